@@ -1,0 +1,192 @@
+/*
+ * jackalope_hip.h -- C ABI of libjackalope_hip.so: jackalope's HTS read-generation hot path
+ * (illumina() / pacbio()) on AMD MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  Each entry point replaces one C++ function of the reference
+ * (reference = lucasnell/jackalope v1.1.6; file:line relative to its root) and is what an Rcpp
+ * shim keeping the reference's RcppExports signatures would bind (INTEGRATION.md shows that shim).
+ * Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ *   reference function                                  replaced by
+ *   --------------------------------------------------  -----------------------------------------
+ *   illumina_ref_cpp   src/hts_illumina.cpp:589-649     jk_illumina_ref
+ *   illumina_hap_cpp   src/hts_illumina.cpp:662-739     jk_illumina_hap
+ *   write_reads_cpp_ / write_reads_one_filetype_        jk_session_* (plan, generate, fetch, write)
+ *                      src/hts.h:323-500
+ *   mt_seeds / seeded_pcg (R RNG contract)              jk_seed_source
+ *                      src/pcg.h:37-85
+ *
+ * Semantics kept from the reference: `n_threads` is the number of independent generator streams
+ * ("lanes").  Lane t behaves exactly like OpenMP thread t of the reference: its own pcg64 seeded
+ * from 8 sub-seed words, its own read quota from split_int(), its own per-chromosome quotas from
+ * reads_per_group(), its own gamma-distribution state.  The reference caps n_threads at
+ * omp_get_max_threads() (src/util.h:197-208); here it is the GPU's parallelism and is typically
+ * 2^16..2^20.  Output order is lane-major (all reads of lane 0, then lane 1, ...), which is one of
+ * the interleavings the reference's `#pragma omp critical` pool flush (src/hts.h:401-412) can
+ * produce; with n_threads = 1 it is the reference's exact single-thread output.
+ *
+ * Errors: every function returns JK_OK (0) or a nonzero jk_status; jk_last_error() gives the
+ * message (thread-local).  The reference throws Rcpp::exception (src/util.h:172-176); the shim
+ * re-throws jk_last_error() through Rcpp::stop.
+ */
+#ifndef JACKALOPE_HIP_H
+#define JACKALOPE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum jk_status {
+    JK_OK = 0,
+    JK_ERR_ARG = 1,          /* invalid argument (message mirrors the reference's stop() text where one exists) */
+    JK_ERR_UNSUPPORTED = 2,  /* valid for the reference, not implemented on the GPU path (fails loudly) */
+    JK_ERR_DEVICE = 3,       /* HIP runtime error / no GPU */
+    JK_ERR_IO = 4,           /* output file could not be opened/written (src/io.h:288-290) */
+    JK_ERR_SEEDS = 5,        /* seed source exhausted */
+    JK_ERR_ABORTED = 6       /* abort flag raised (Progress::check_abort, src/hts.h:396-399) */
+} jk_status;
+
+/* View of a RefGenome (src/ref_classes.h:127-180).  Borrowed for the duration of the call. */
+typedef struct jk_ref_genome {
+    uint64_t n_chroms;
+    const char* const* chrom_names;   /* RefChrom::name   */
+    const char* const* chrom_seqs;    /* RefChrom::nucleos, chrom_lens[i] bytes, need not be NUL-terminated */
+    const uint64_t* chrom_lens;
+    const char* name;                 /* RefGenome::name, "REF" (src/ref_classes.h:138); NULL = "REF" */
+} jk_ref_genome;
+
+/* View of a HapSet (src/hap_classes.h:500-611): for haplotype h and chromosome c, cell = h*n_chroms+c.
+ * Mutations of all cells are concatenated in cell order; mutation m of the set has old_pos[m],
+ * new_pos[m] (AllMutations, src/hap_classes.h:100-104) and inserted/substituted bytes
+ * nuc_blob[nuc_off[m] .. nuc_off[m+1]) (empty = deletion, the reference's nullptr). */
+typedef struct jk_hap_set {
+    uint64_t n_haps, n_chroms;
+    const char* const* hap_names;     /* HapGenome::name, "hap0".. */
+    jk_ref_genome ref;
+    const uint64_t* chrom_size;       /* [n_haps*n_chroms] HapChrom::chrom_size */
+    const uint64_t* n_mut;            /* [n_haps*n_chroms] */
+    const uint64_t* old_pos;          /* [sum n_mut] */
+    const uint64_t* new_pos;          /* [sum n_mut] */
+    const uint64_t* nuc_off;          /* [sum n_mut + 1] */
+    const char* nuc_blob;
+} jk_hap_set;
+
+/* qual_probs / quals of one read end as illumina_ref_cpp receives them
+ * (vector<vector<vector<double>>>, [nt T,C,A,G][position][k]; src/hts_illumina.cpp:604-609), flattened. */
+typedef struct jk_illumina_profile {
+    uint32_t read_length;
+    const uint32_t* n_quals;          /* [4*read_length], nt-major */
+    const double* probs;              /* flat, same order */
+    const uint8_t* quals;             /* flat, same order (uint8 = unsigned char, src/jackalope_types.h:26) */
+} jk_illumina_profile;
+
+/* Where the 32-bit sub-seed words come from.  The reference draws them from R's RNG with
+ * Rcpp::runif(8, 0, 4294967296) truncated to integers (src/pcg.h:37-46,63-71), in this order:
+ * 8 per lane for all lanes (mt_seeds, src/hts.h:339), then 8 per reads_per_group() call that has
+ * n_reads > 0 (src/hts.h:62-64), lane by lane (src/hts.h:349-353).  Either give the words up front
+ * (`words`/`n_words`) or a callback that fills the next 8. */
+typedef int (*jk_seed_fn)(void* user, uint32_t* out8);
+typedef struct jk_seed_source {
+    const uint32_t* words;
+    uint64_t n_words;
+    jk_seed_fn fn;
+    void* user;
+} jk_seed_source;
+
+/* Arguments of illumina_ref_cpp / illumina_hap_cpp, same names and meaning
+ * (src/hts_illumina.cpp:589-612, :662-687). */
+typedef struct jk_illumina_args {
+    int32_t paired;
+    int32_t matepair;
+    const char* out_prefix;           /* files <prefix>_R1.fq[, <prefix>_R2.fq] (src/hts.h:342-346) */
+    int32_t sep_files;                /* hap only: one pair of files per haplotype (src/hts.h:512-552) */
+    int32_t compress;                 /* only 0 is implemented on this path (JK_ERR_UNSUPPORTED otherwise) */
+    const char* comp_method;
+    uint64_t n_reads;
+    double prob_dup;
+    uint64_t n_threads;               /* number of lanes, see header comment */
+    int32_t show_progress;            /* accepted, ignored (no progress bar) */
+    uint64_t read_pool_size;
+    const double* haplotype_probs;    /* hap only, [n_haps] */
+    double frag_len_shape, frag_len_scale;
+    uint64_t frag_len_min, frag_len_max;
+    jk_illumina_profile profile1; double ins_prob1, del_prob1;
+    jk_illumina_profile profile2; double ins_prob2, del_prob2;   /* ignored unless paired */
+    const char* const* barcodes;      /* ref: barcodes[0]; hap: one per haplotype (padded with "") */
+    uint64_t n_barcodes;
+    jk_seed_source seeds;
+    const volatile int32_t* abort_flag;   /* may be NULL; polled between batches */
+    /* Sharding for multi-GPU runs: this process generates lanes [lane_begin, lane_end) of the
+     * n_threads lanes (all seeds/quotas are still derived for every lane, so every rank agrees).
+     * lane_end = 0 means n_threads. */
+    uint64_t lane_begin, lane_end;
+    int32_t device;                   /* HIP device ordinal */
+    uint64_t max_batch_bytes;         /* cap on device memory for one batch's read pools; 0 = default */
+} jk_illumina_args;
+
+const char* jk_last_error(void);
+const char* jk_version(void);
+
+/* One-shot entry points: generate and write the FASTQ files, like the reference's functions. */
+int jk_illumina_ref(const jk_ref_genome* genome, const jk_illumina_args* args);
+int jk_illumina_hap(const jk_hap_set* haps, const jk_illumina_args* args);
+
+/* Session API (what the one-shot calls are made of; used by tests and bench.py so that the
+ * generated FASTQ can stay resident in HBM). */
+typedef struct jk_session jk_session;
+
+int jk_illumina_ref_open(const jk_ref_genome* genome, const jk_illumina_args* args, jk_session** out);
+int jk_illumina_hap_open(const jk_hap_set* haps, const jk_illumina_args* args, jk_session** out);
+/* Run every batch of this session's lanes: generator kernel, per-lane byte-count scan, pool
+ * compaction into the lane-major FASTQ images.  May be called repeatedly (same output each time). */
+int jk_session_generate(jk_session* s);
+/* bytes[e] = FASTQ bytes of read end e (e < n_ends); reads = reads made (all ends). */
+int jk_session_sizes(const jk_session* s, uint64_t bytes[2], uint64_t* reads, uint32_t* n_ends);
+/* Device pointer of the FASTQ image of read end e (valid until the next generate/close). */
+int jk_session_device_ptr(const jk_session* s, uint32_t end, const void** dptr);
+/* Copy the FASTQ image of read end e to host memory (cap >= bytes[e]). */
+int jk_session_fetch(const jk_session* s, uint32_t end, void* dst, uint64_t cap);
+/* Write <out_prefix>_R<e+1>.fq for every end (uncompressed, FileUncomp src/io.h:242-295). */
+int jk_session_write(const jk_session* s);
+/* Timing of the last generate(): HIP-event milliseconds on the session's stream.
+ * ms[0] generator kernel(s), ms[1] scan + compaction kernels, ms[2] whole generate() (device). */
+int jk_session_timing(const jk_session* s, double ms[3]);
+/* Number of sub-seed words consumed while opening the session. */
+uint64_t jk_session_seed_words_used(const jk_session* s);
+/* Per-lane counts, for the multi-GPU count/offset exchange: n = lane_end - lane_begin entries. */
+int jk_session_lane_bytes(const jk_session* s, uint32_t end, uint64_t* out, uint64_t n);
+void jk_session_close(jk_session* s);
+
+/* Host-side pieces of the path that the shim or tests may want on their own. */
+void jk_split_int(uint64_t x, uint64_t n, uint64_t* out);                         /* src/util.h:245-258 */
+int jk_reads_per_group(uint64_t n_reads, const double* probs, uint64_t n,         /* src/hts.h:58-103 */
+                       jk_seed_source* seeds, uint64_t* out);
+void jk_alias_build(const double* probs, uint64_t n, double* Prob, uint64_t* Alias);   /* src/alias_sampler.h:68-106 */
+int jk_hap_chrom_full(const jk_hap_set* haps, uint64_t hap, uint64_t chrom, char* out, uint64_t cap); /* src/hap_classes.cpp:80-116 (host) */
+
+/* Elementary arithmetic of the path evaluated by the SAME inline functions the kernels use, on the
+ * host (`jk_host_*`) and on the device (`jk_dev_*`, arrays of n inputs already in host memory; they
+ * are copied to the GPU, evaluated there by one thread per element and copied back).  These exist
+ * so that tests can compare each primitive with the oracle.  `what`: */
+enum {
+    JK_OP_PCG_STREAM = 0,   /* in: 8 seed words per stream (as u64[8] each), out: `aux` outputs per stream */
+    JK_OP_RUNIF_INDEX = 1,  /* in: x, aux = n            -> (uint64)(runif_01 * n)          */
+    JK_OP_RUNIF_DOUBLE = 2, /* in: x                     -> bits of (double)runif_01         */
+    JK_OP_CANONICAL = 3,    /* in: x                     -> bits of generate_canonical       */
+    JK_OP_N_QUAL = 4,       /* in: x                     -> runif_01*10 + '!' as uint8       */
+    JK_OP_LT_HALF = 5,      /* in: x                     -> runif_01 < 0.5                   */
+    JK_OP_FRAG_START = 6,   /* in: x, aux = span         -> (uint64)(u * span)               */
+    JK_OP_LOG = 7,          /* in: bits of a double      -> bits of log                      */
+    JK_OP_SQRT = 8,         /* in: bits of a double      -> bits of sqrt                     */
+    JK_OP_GAMMA_STREAM = 9  /* in: 8 seed words per stream, out: `aux` gamma(16,25)-style draws (bits); shape/scale via jk_dev_set_gamma */
+};
+int jk_host_eval(int what, const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out);
+int jk_dev_eval(int device, int what, const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out);
+void jk_eval_set_gamma(double shape, double scale);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JACKALOPE_HIP_H */

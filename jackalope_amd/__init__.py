@@ -1,0 +1,13 @@
+"""jackalope_amd -- MI355X-native HTS read generation behind jackalope's illumina()/pacbio() API.
+
+Only what the hot path needs lives here: ``csrc/`` (HIP kernels + the C ABI of
+include/jackalope_hip.h) and the host-side mirror of the reference's R-level interface.
+"""
+from ._abi import JackalopeHipError, lib  # noqa: F401
+from .genome import RefGenome, synthetic_genome  # noqa: F401
+from .illumina import illumina, IlluminaSession  # noqa: F401
+from .profiles import read_profile, Profile  # noqa: F401
+from .rng import seed_words  # noqa: F401
+
+__all__ = ["illumina", "IlluminaSession", "RefGenome", "synthetic_genome", "read_profile", "Profile", "seed_words",
+           "JackalopeHipError", "lib"]

@@ -1,0 +1,146 @@
+"""ctypes binding of libjackalope_hip.so (include/jackalope_hip.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no
+CPU fallback: if the library is missing or a HIP call fails, the error is raised to the caller.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libjackalope_hip.so")
+
+JK_OK = 0
+JK_ERR_ARG, JK_ERR_UNSUPPORTED, JK_ERR_DEVICE, JK_ERR_IO, JK_ERR_SEEDS, JK_ERR_ABORTED = 1, 2, 3, 4, 5, 6
+
+(OP_PCG_STREAM, OP_RUNIF_INDEX, OP_RUNIF_DOUBLE, OP_CANONICAL, OP_N_QUAL, OP_LT_HALF, OP_FRAG_START,
+ OP_LOG, OP_SQRT, OP_GAMMA_STREAM) = range(10)
+
+
+class JackalopeHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("jackalope_hip error %d: %s" % (code, msg))
+        self.code = code
+        self.message = msg
+
+
+class RefGenomeView(C.Structure):
+    _fields_ = [("n_chroms", C.c_uint64),
+                ("chrom_names", C.POINTER(C.c_char_p)),
+                ("chrom_seqs", C.POINTER(C.c_void_p)),
+                ("chrom_lens", C.POINTER(C.c_uint64)),
+                ("name", C.c_char_p)]
+
+
+class HapSetView(C.Structure):
+    _fields_ = [("n_haps", C.c_uint64), ("n_chroms", C.c_uint64),
+                ("hap_names", C.POINTER(C.c_char_p)),
+                ("ref", RefGenomeView),
+                ("chrom_size", C.POINTER(C.c_uint64)),
+                ("n_mut", C.POINTER(C.c_uint64)),
+                ("old_pos", C.POINTER(C.c_uint64)),
+                ("new_pos", C.POINTER(C.c_uint64)),
+                ("nuc_off", C.POINTER(C.c_uint64)),
+                ("nuc_blob", C.c_void_p)]
+
+
+class IlluminaProfile(C.Structure):
+    _fields_ = [("read_length", C.c_uint32),
+                ("n_quals", C.POINTER(C.c_uint32)),
+                ("probs", C.POINTER(C.c_double)),
+                ("quals", C.POINTER(C.c_uint8))]
+
+
+SEED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32))
+
+
+class SeedSource(C.Structure):
+    _fields_ = [("words", C.POINTER(C.c_uint32)),
+                ("n_words", C.c_uint64),
+                ("fn", SEED_FN),
+                ("user", C.c_void_p)]
+
+
+class IlluminaArgs(C.Structure):
+    _fields_ = [("paired", C.c_int32), ("matepair", C.c_int32),
+                ("out_prefix", C.c_char_p),
+                ("sep_files", C.c_int32), ("compress", C.c_int32),
+                ("comp_method", C.c_char_p),
+                ("n_reads", C.c_uint64), ("prob_dup", C.c_double),
+                ("n_threads", C.c_uint64), ("show_progress", C.c_int32),
+                ("read_pool_size", C.c_uint64),
+                ("haplotype_probs", C.POINTER(C.c_double)),
+                ("frag_len_shape", C.c_double), ("frag_len_scale", C.c_double),
+                ("frag_len_min", C.c_uint64), ("frag_len_max", C.c_uint64),
+                ("profile1", IlluminaProfile), ("ins_prob1", C.c_double), ("del_prob1", C.c_double),
+                ("profile2", IlluminaProfile), ("ins_prob2", C.c_double), ("del_prob2", C.c_double),
+                ("barcodes", C.POINTER(C.c_char_p)), ("n_barcodes", C.c_uint64),
+                ("seeds", SeedSource),
+                ("abort_flag", C.POINTER(C.c_int32)),
+                ("lane_begin", C.c_uint64), ("lane_end", C.c_uint64),
+                ("device", C.c_int32),
+                ("max_batch_bytes", C.c_uint64)]
+
+
+# every symbol include/jackalope_hip.h declares
+EXPORTS = [
+    "jk_last_error", "jk_version", "jk_illumina_ref", "jk_illumina_hap",
+    "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_session_generate", "jk_session_sizes",
+    "jk_session_device_ptr", "jk_session_fetch", "jk_session_write", "jk_session_timing",
+    "jk_session_seed_words_used", "jk_session_lane_bytes", "jk_session_close",
+    "jk_split_int", "jk_reads_per_group", "jk_alias_build", "jk_hap_chrom_full",
+    "jk_host_eval", "jk_dev_eval", "jk_eval_set_gamma",
+]
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise JackalopeHipError(JK_ERR_DEVICE, "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so (same SONAME as the system
+    # one).  Whichever is mapped first serves both, so let torch map its copy before ours is resolved;
+    # otherwise two runtimes end up loaded and the second one to initialise sees no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    L.jk_last_error.restype = C.c_char_p
+    L.jk_version.restype = C.c_char_p
+    L.jk_session_seed_words_used.restype = C.c_uint64
+    L.jk_session_seed_words_used.argtypes = [C.c_void_p]
+    L.jk_illumina_ref.argtypes = [C.POINTER(RefGenomeView), C.POINTER(IlluminaArgs)]
+    L.jk_illumina_hap.argtypes = [C.POINTER(HapSetView), C.POINTER(IlluminaArgs)]
+    L.jk_illumina_ref_open.argtypes = [C.POINTER(RefGenomeView), C.POINTER(IlluminaArgs), C.POINTER(C.c_void_p)]
+    L.jk_illumina_hap_open.argtypes = [C.POINTER(HapSetView), C.POINTER(IlluminaArgs), C.POINTER(C.c_void_p)]
+    L.jk_session_generate.argtypes = [C.c_void_p]
+    L.jk_session_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.jk_session_device_ptr.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+    L.jk_session_fetch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+    L.jk_session_write.argtypes = [C.c_void_p]
+    L.jk_session_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.jk_session_lane_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+    L.jk_session_close.argtypes = [C.c_void_p]
+    L.jk_session_close.restype = None
+    L.jk_split_int.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
+    L.jk_split_int.restype = None
+    L.jk_reads_per_group.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(SeedSource), C.c_void_p]
+    L.jk_alias_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.jk_alias_build.restype = None
+    L.jk_hap_chrom_full.argtypes = [C.POINTER(HapSetView), C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
+    L.jk_host_eval.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.jk_dev_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.jk_eval_set_gamma.argtypes = [C.c_double, C.c_double]
+    L.jk_eval_set_gamma.restype = None
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != JK_OK:
+        raise JackalopeHipError(rc, lib().jk_last_error().decode("utf-8", "replace"))

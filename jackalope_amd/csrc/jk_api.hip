@@ -1,0 +1,606 @@
+// jk_api.hip -- C ABI (include/jackalope_hip.h) of the MI355X read-generation path: host driver
+// (the GPU counterpart of write_reads_cpp_ / write_reads_one_filetype_, reference src/hts.h:323-500)
+// around the kernels in jk_illumina_kernel.h.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/jackalope_hip.h"
+#include "jk_host.h"
+#include "jk_illumina_kernel.h"
+
+namespace jk {
+
+static thread_local std::string g_last_error;
+
+#define JK_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            throw Error(JK_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void alloc(size_t bytes) {
+        release();
+        if (bytes == 0) bytes = 16;
+        JK_HIP(hipMalloc(&p, bytes));
+        n = bytes;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+    template <typename T> void upload(const std::vector<T>& v) {
+        alloc(v.size() * sizeof(T));
+        if (!v.empty()) JK_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+};
+
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+static inline uint32_t n_digits(uint64_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; d++; } return d; }
+
+struct Batch {
+    uint64_t lane0;        // first lane (relative to the shard)
+    uint32_t n_lanes;
+    uint64_t pool_bytes;   // per read end
+};
+
+}  // namespace jk
+
+using namespace jk;
+
+struct jk_session {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t n_ends = 1;
+    bool paired = false;
+    std::string out_prefix;
+    // genome
+    DevBuf d_seq, d_chrom_off, d_chrom_len, d_hdr_blob, d_hdr_off;
+    uint32_t n_chroms = 0;
+    // tables
+    IlluminaTables tables;
+    DevBuf d_info, d_thresh, d_quals, d_mm;
+    bool lds_tables = false;
+    size_t lds_bytes = 0;
+    // lanes of this shard
+    uint64_t n_lanes_total = 0, lane_begin = 0, lane_end = 0, n_shard = 0;
+    std::vector<uint64_t> pool_off_host;          // per batch-relative offsets, concatenated per batch (n+1 each)
+    DevBuf d_seeds, d_lane_reads, d_chrom_reads, d_pool_off;
+    std::vector<Batch> batches;
+    std::vector<uint64_t> batch_pool_off_index;   // index into d_pool_off of each batch's first entry
+    DevBuf d_pool[2], d_out[2], d_lane_bytes[2], d_lane_off[2], d_block_sums, d_base[2], d_lane_made, d_evw, d_err;
+    uint64_t out_cap = 0;
+    IlluminaKernelParams kp{};                    // template, per-batch fields filled at launch
+    // results of the last generate()
+    uint64_t bytes[2] = {0, 0};
+    uint64_t reads_made = 0;
+    double ms[3] = {0, 0, 0};
+    bool generated = false;
+    uint64_t seed_words_used = 0;
+    const volatile int32_t* abort_flag = nullptr;
+    std::vector<hipEvent_t> events;
+
+    ~jk_session() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace jk {
+
+static void upload_genome(jk_session& s, const jk_ref_genome& g) {
+    if (g.n_chroms == 0) throw Error(JK_ERR_ARG, "reference genome has no chromosomes");
+    if (g.n_chroms > 0xffffffffULL) throw Error(JK_ERR_UNSUPPORTED, "too many chromosomes");
+    const std::string gname = g.name ? g.name : "REF";
+    std::vector<uint64_t> off(g.n_chroms), len(g.n_chroms);
+    uint64_t total = 64;
+    for (uint64_t i = 0; i < g.n_chroms; i++) { off[i] = total; len[i] = g.chrom_lens[i]; total = align_up(total + len[i], 64) + 64; }
+    s.d_seq.alloc(total);
+    JK_HIP(hipMemset(s.d_seq.p, 'N', total));
+    for (uint64_t i = 0; i < g.n_chroms; i++)
+        if (len[i]) JK_HIP(hipMemcpy(s.d_seq.as<uint8_t>() + off[i], g.chrom_seqs[i], len[i], hipMemcpyHostToDevice));
+    std::vector<uint8_t> blob;
+    std::vector<uint32_t> hoff(g.n_chroms + 1);
+    for (uint64_t i = 0; i < g.n_chroms; i++) {
+        hoff[i] = (uint32_t)blob.size();
+        std::string h = "@" + gname + "-" + (g.chrom_names ? g.chrom_names[i] : "") + "-";
+        blob.insert(blob.end(), h.begin(), h.end());
+    }
+    hoff[g.n_chroms] = (uint32_t)blob.size();
+    s.d_chrom_off.upload(off);
+    s.d_chrom_len.upload(len);
+    s.d_hdr_blob.upload(blob);
+    s.d_hdr_off.upload(hoff);
+    s.n_chroms = (uint32_t)g.n_chroms;
+}
+
+// Everything the reference does on the calling thread before the parallel region, plus device set-up.
+static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_illumina_args& a) {
+    if (a.compress > 0) throw Error(JK_ERR_UNSUPPORTED, "compressed FASTQ output is not implemented on the GPU path (write uncompressed, then gzip/bgzip)");
+    if (a.frag_len_shape < 1.0) throw Error(JK_ERR_UNSUPPORTED, "frag_len_shape < 1 (fragment sd > mean) is not implemented on the GPU path");
+    if (!(a.frag_len_scale > 0)) throw Error(JK_ERR_ARG, "frag_len_scale must be > 0");
+    s.paired = a.paired != 0;
+    s.n_ends = s.paired ? 2 : 1;
+    s.out_prefix = a.out_prefix ? a.out_prefix : "";
+    s.abort_flag = a.abort_flag;
+    s.device = a.device;
+    JK_HIP(hipSetDevice(s.device));
+    JK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+
+    s.tables = build_illumina_tables(a);
+    const uint32_t L = s.tables.read_length;
+    const std::string barcode = (a.barcodes && a.n_barcodes > 0 && a.barcodes[0]) ? a.barcodes[0] : "";
+    if (barcode.size() > (size_t)JK_MAX_BARCODE) throw Error(JK_ERR_UNSUPPORTED, "barcodes longer than 32 bases are not implemented on the GPU path");
+    if (barcode.size() >= L) throw Error(JK_ERR_ARG, "barcode must be shorter than the read length");
+    const uint32_t ev_words = (2 * L + 63) / 64 + 1;
+    if (ev_words > (uint32_t)JK_MAX_EVW) throw Error(JK_ERR_UNSUPPORTED, "read lengths above 480 are not implemented on the GPU path");
+
+    upload_genome(s, g);
+    uint64_t min_chrom = ~0ULL, max_chrom = 0;
+    size_t max_hdr = 0;
+    const std::string gname = g.name ? g.name : "REF";
+    for (uint64_t i = 0; i < g.n_chroms; i++) {
+        min_chrom = std::min<uint64_t>(min_chrom, g.chrom_lens[i]);
+        max_chrom = std::max<uint64_t>(max_chrom, g.chrom_lens[i]);
+        max_hdr = std::max(max_hdr, 3 + gname.size() + std::strlen(g.chrom_names ? g.chrom_names[i] : ""));
+    }
+    const uint64_t frag_lb = std::min<uint64_t>(a.frag_len_min <= a.frag_len_max ? a.frag_len_min : a.frag_len_max, min_chrom);
+    if (frag_lb < std::max<uint64_t>(barcode.size(), 1))
+        throw Error(JK_ERR_UNSUPPORTED, "fragments shorter than the barcode (or empty) are not implemented on the GPU path");
+
+    // ---- lanes, quotas, seeds: same order of seed consumption as src/hts.h:334-353
+    uint64_t T = a.n_threads ? a.n_threads : 1;
+    s.n_lanes_total = T;
+    s.lane_begin = a.lane_begin;
+    s.lane_end = a.lane_end ? a.lane_end : T;
+    if (s.lane_begin > s.lane_end || s.lane_end > T) throw Error(JK_ERR_ARG, "lane shard out of range");
+    s.n_shard = s.lane_end - s.lane_begin;
+    std::vector<uint64_t> per_lane = split_int(a.n_reads / s.n_ends, T);
+    for (uint64_t& v : per_lane) v *= s.n_ends;
+    if (per_lane[0] > 0xffffffffULL) throw Error(JK_ERR_UNSUPPORTED, "more than 2^32 reads per lane: raise n_threads");
+
+    SeedReader seeds{a.seeds};
+    std::vector<uint32_t> lane_seeds(s.n_shard * 8);
+    {
+        uint32_t w[8];
+        for (uint64_t t = 0; t < T; t++) {
+            seeds.take8(w);
+            if (t >= s.lane_begin && t < s.lane_end) std::memcpy(&lane_seeds[(t - s.lane_begin) * 8], w, sizeof(w));
+        }
+    }
+    std::vector<uint64_t> lane_reads(s.n_shard);
+    std::vector<uint32_t> chrom_reads((size_t)s.n_chroms * s.n_shard, 0);
+    std::vector<double> chrom_probs(g.chrom_lens, g.chrom_lens + g.n_chroms);
+    for (uint64_t t = 0; t < T; t++) {
+        // IlluminaOneGenome::add_n_reads (src/hts_illumina.h:410-418)
+        uint64_t n = per_lane[t];
+        if (s.paired) n /= 2;
+        const bool mine = t >= s.lane_begin && t < s.lane_end;
+        if (!mine) {                       // only keep the seed stream in step
+            if (n > 0) { uint32_t w[8]; seeds.take8(w); }
+            continue;
+        }
+        const uint64_t l = t - s.lane_begin;
+        lane_reads[l] = per_lane[t];
+        std::vector<uint64_t> cr = reads_per_group(n, chrom_probs, seeds);
+        for (uint32_t c = 0; c < s.n_chroms; c++) {
+            uint64_t v = cr[c] * (s.paired ? 2 : 1);
+            chrom_reads[(size_t)c * s.n_shard + l] = (uint32_t)v;
+        }
+    }
+    s.seed_words_used = seeds.pos;
+
+    // ---- pools: one region per lane, big enough for its quota of maximal records
+    const uint64_t rec_max = max_hdr + n_digits(max_chrom) + 2 + (s.paired ? 2 : 0) + 1 + (uint64_t)L + 3 + L + 1;
+    const uint64_t max_batch = a.max_batch_bytes ? a.max_batch_bytes : (8ULL << 30);
+    const uint64_t max_batch_lanes = 1ULL << 22;
+    std::vector<uint64_t> pool_off;    // concatenation over batches of (n_lanes+1) relative offsets
+    uint64_t out_cap = 0, max_pool = 0;
+    uint32_t max_lanes = 0;
+    {
+        uint64_t l = 0;
+        while (l < s.n_shard) {
+            Batch b{l, 0, 0};
+            s.batch_pool_off_index.push_back(pool_off.size());
+            pool_off.push_back(0);
+            uint64_t used = 0;
+            while (l < s.n_shard && b.n_lanes < max_batch_lanes) {
+                const uint64_t cap = align_up((lane_reads[l] / s.n_ends) * rec_max, 16);
+                if (b.n_lanes > 0 && used + cap > max_batch) break;
+                used += cap; pool_off.push_back(used); b.n_lanes++; l++;
+            }
+            b.pool_bytes = used;
+            out_cap += used;
+            max_pool = std::max(max_pool, used);
+            max_lanes = std::max(max_lanes, b.n_lanes);
+            s.batches.push_back(b);
+        }
+    }
+    s.out_cap = out_cap;
+
+    // ---- device state
+    s.d_seeds.upload(lane_seeds);
+    s.d_lane_reads.upload(lane_reads);
+    s.d_chrom_reads.upload(chrom_reads);
+    s.d_pool_off.upload(pool_off);
+    s.d_info.upload(s.tables.info);
+    s.d_thresh.upload(s.tables.thresh);
+    s.d_quals.upload(s.tables.quals);
+    s.d_mm.upload(s.tables.mm_thresh);
+    for (uint32_t e = 0; e < s.n_ends; e++) {
+        s.d_pool[e].alloc(max_pool + 64);
+        s.d_out[e].alloc(out_cap + 64);
+        s.d_lane_bytes[e].alloc(s.n_shard * 8);
+        s.d_lane_off[e].alloc(s.n_shard * 8);
+        s.d_base[e].alloc((s.batches.size() + 1) * 8);
+    }
+    s.d_lane_made.alloc(s.n_shard * 8);
+    s.d_block_sums.alloc((max_lanes / SCAN_BLOCK + 2) * 8);
+    s.d_evw.alloc((size_t)s.n_ends * 4 * ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
+    s.d_err.alloc(4);
+
+    s.lds_bytes = s.tables.thresh.size() * 8 + 256 * 8 + s.tables.info.size() * 4 + align_up(s.tables.quals.size() * 2, 16);
+    s.lds_tables = s.lds_bytes <= 150 * 1024;
+
+    IlluminaKernelParams& P = s.kp;
+    P.g.seq = s.d_seq.as<uint8_t>();
+    P.g.chrom_off = s.d_chrom_off.as<uint64_t>();
+    P.g.chrom_len = s.d_chrom_len.as<uint64_t>();
+    P.g.hdr_blob = s.d_hdr_blob.as<uint8_t>();
+    P.g.hdr_off = s.d_hdr_off.as<uint32_t>();
+    P.g.n_chroms = s.n_chroms;
+    P.evw = s.d_evw.as<uint64_t>();
+    P.err = s.d_err.as<uint32_t>();
+    P.read_len = L; P.n_ends = s.n_ends; P.paired = s.paired; P.matepair = (s.paired && a.matepair) ? 1 : 0;
+    P.ev_words = ev_words;
+    P.frag_min = a.frag_len_min; P.frag_max = a.frag_len_max;
+    {   // gamma_distribution<double>::param_type::_M_initialize (random.tcc:2330-2346), alpha >= 1
+        const double a1 = a.frag_len_shape - 1.0 / 3.0;
+        P.gp.a1 = a1;
+        P.gp.a2 = 1.0 / std::sqrt(9.0 * a1);
+        P.gp.beta = a.frag_len_scale;
+    }
+    const double insp[2] = {a.ins_prob1, a.ins_prob2}, delp[2] = {a.del_prob1, a.del_prob2};
+    for (uint32_t r = 0; r < 2; r++) {
+        // u > (ins + del) -> match ; else u > ins -> deletion ; else insertion (hts_illumina.cpp:133-144)
+        Threshold tm = threshold_le(insp[r] + delp[r]);
+        Threshold td = threshold_le(insp[r]);
+        P.th_match[r] = tm.th; P.never_match[r] = tm.all;
+        P.th_del[r] = td.th; P.never_del[r] = td.all;
+    }
+    {   // dup < prob_dup (src/hts.h:265-266)
+        Threshold t = threshold_lt(a.prob_dup);
+        P.th_dup = t.th; P.dup_all = t.all;
+    }
+    P.pool_size = a.read_pool_size;
+    P.bc_len = (uint32_t)barcode.size();
+    std::memset(P.barcode, 0, sizeof(P.barcode));
+    std::memcpy(P.barcode, barcode.data(), barcode.size());
+    P.info = s.d_info.as<uint32_t>(); P.thresh = s.d_thresh.as<uint64_t>();
+    P.quals = s.d_quals.as<uint16_t>(); P.mm_thresh = s.d_mm.as<uint64_t>();
+    P.n_info = (uint32_t)s.tables.info.size(); P.n_entries = (uint32_t)s.tables.thresh.size();
+
+    const size_t n_ev = 2 + 2 * s.batches.size() + 2;
+    s.events.resize(n_ev);
+    for (hipEvent_t& e : s.events) JK_HIP(hipEventCreate(&e));
+
+    if (s.lds_tables) {
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
+    }
+}
+
+static void launch_generate(jk_session& s) {
+    JK_HIP(hipSetDevice(s.device));
+    JK_HIP(hipMemsetAsync(s.d_err.p, 0, 4, s.stream));
+    for (uint32_t e = 0; e < s.n_ends; e++) JK_HIP(hipMemsetAsync(s.d_base[e].p, 0, 8, s.stream));
+    size_t ev = 0;
+    JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+    for (size_t b = 0; b < s.batches.size(); b++) {
+        if (s.abort_flag && *s.abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
+        const Batch& B = s.batches[b];
+        IlluminaKernelParams P = s.kp;
+        P.n_lanes = B.n_lanes;
+        P.seeds = s.d_seeds.as<uint32_t>() + B.lane0 * 8;
+        P.lane_reads = s.d_lane_reads.as<uint64_t>() + B.lane0;
+        // chromosome-major layout over the whole shard: row stride = n_shard.  The kernel indexes
+        // chrom_reads[ci * n_lanes + lane], so give it a per-batch view only when the batch is the shard.
+        P.chrom_reads = s.d_chrom_reads.as<uint32_t>() + B.lane0;
+        P.pool_off = s.d_pool_off.as<uint64_t>() + s.batch_pool_off_index[b];
+        for (uint32_t e = 0; e < 2; e++) {
+            P.pool[e] = e < s.n_ends ? s.d_pool[e].as<uint8_t>() : nullptr;
+            P.lane_bytes[e] = e < s.n_ends ? s.d_lane_bytes[e].as<uint64_t>() + B.lane0 : nullptr;
+        }
+        P.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
+        P.chrom_stride = (uint32_t)s.n_shard;
+        const uint32_t block = 1024;
+        const uint32_t grid = (B.n_lanes + block - 1) / block;
+        JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+        if (s.lds_tables) {
+            if (s.n_ends == 2) hipLaunchKernelGGL((illumina_ref_kernel<true, 2>), dim3(grid), dim3(block), s.lds_bytes, s.stream, P);
+            else hipLaunchKernelGGL((illumina_ref_kernel<true, 1>), dim3(grid), dim3(block), s.lds_bytes, s.stream, P);
+        } else {
+            if (s.n_ends == 2) hipLaunchKernelGGL((illumina_ref_kernel<false, 2>), dim3(grid), dim3(block), 0, s.stream, P);
+            else hipLaunchKernelGGL((illumina_ref_kernel<false, 1>), dim3(grid), dim3(block), 0, s.stream, P);
+        }
+        JK_HIP(hipGetLastError());
+        JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+        const uint32_t nb = (B.n_lanes + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        for (uint32_t e = 0; e < s.n_ends; e++) {
+            uint64_t* lb = s.d_lane_bytes[e].as<uint64_t>() + B.lane0;
+            uint64_t* lo = s.d_lane_off[e].as<uint64_t>() + B.lane0;
+            uint64_t* bs = s.d_block_sums.as<uint64_t>();
+            uint64_t* base = s.d_base[e].as<uint64_t>() + b;
+            hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s.stream, lb, lo, bs, B.n_lanes);
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.stream, bs, nb, base);
+            hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s.stream, lo, bs, B.n_lanes);
+            hipLaunchKernelGGL(compact_pools_kernel, dim3((B.n_lanes + 3) / 4), dim3(256), 0, s.stream,
+                               s.d_pool[e].as<uint8_t>(), P.pool_off, lb, lo, s.d_out[e].as<uint8_t>(), base, B.n_lanes);
+            JK_HIP(hipGetLastError());
+        }
+    }
+    JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+    JK_HIP(hipStreamSynchronize(s.stream));
+
+    uint32_t err = 0;
+    JK_HIP(hipMemcpy(&err, s.d_err.p, 4, hipMemcpyDeviceToHost));
+    if (err & JK_KERR_POOL_OVERFLOW) throw Error(JK_ERR_DEVICE, "internal error: a lane overflowed its pool region");
+    if (err & JK_KERR_TOO_MANY_DELETIONS) throw Error(JK_ERR_UNSUPPORTED, "a read needed more than 2x read_length reference positions (deletion probability too high for the GPU path)");
+    for (uint32_t e = 0; e < s.n_ends; e++)
+        JK_HIP(hipMemcpy(&s.bytes[e], s.d_base[e].as<uint64_t>() + s.batches.size(), 8, hipMemcpyDeviceToHost));
+    {
+        std::vector<uint64_t> made(s.n_shard);
+        if (s.n_shard) JK_HIP(hipMemcpy(made.data(), s.d_lane_made.p, s.n_shard * 8, hipMemcpyDeviceToHost));
+        s.reads_made = 0;
+        for (uint64_t v : made) s.reads_made += v;
+    }
+    float t = 0;
+    double gen = 0, rest = 0;
+    for (size_t b = 0; b < s.batches.size(); b++) {
+        JK_HIP(hipEventElapsedTime(&t, s.events[1 + 2 * b], s.events[2 + 2 * b]));
+        gen += t;
+    }
+    JK_HIP(hipEventElapsedTime(&t, s.events[0], s.events[ev - 1]));
+    rest = t - gen;
+    s.ms[0] = gen; s.ms[1] = rest; s.ms[2] = t;
+    s.generated = true;
+}
+
+static void write_files(const jk_session& s) {
+    if (!s.generated) throw Error(JK_ERR_ARG, "jk_session_write before jk_session_generate");
+    const size_t CH = 64u << 20;
+    std::vector<char> buf(CH);
+    for (uint32_t e = 0; e < s.n_ends; e++) {
+        const std::string fn = s.out_prefix + "_R" + std::to_string(e + 1) + ".fq";
+        FILE* f = std::fopen(fn.c_str(), "wb");
+        if (!f) throw Error(JK_ERR_IO, "Unable to open file " + fn + ".\n");
+        for (uint64_t off = 0; off < s.bytes[e]; off += CH) {
+            const size_t n = (size_t)std::min<uint64_t>(CH, s.bytes[e] - off);
+            hipError_t he = hipMemcpy(buf.data(), s.d_out[e].as<uint8_t>() + off, n, hipMemcpyDeviceToHost);
+            if (he != hipSuccess) { std::fclose(f); throw Error(JK_ERR_DEVICE, hipGetErrorString(he)); }
+            if (std::fwrite(buf.data(), 1, n, f) != n) { std::fclose(f); throw Error(JK_ERR_IO, "short write to " + fn); }
+        }
+        if (std::fclose(f) != 0) throw Error(JK_ERR_IO, "error closing " + fn);
+    }
+}
+
+// ---- primitive evaluation hooks ---------------------------------------------------------------
+static double g_eval_shape = 16.0, g_eval_scale = 25.0;
+
+struct EvalRng { jk_pcg64 e; JK_HD uint64_t operator()() { return jk_pcg_next(e); } };
+
+JK_HD void eval_one(int what, const uint64_t* in, uint64_t i, uint64_t aux, uint64_t* out, jk_gamma_param gp) {
+    switch (what) {
+        case JK_OP_PCG_STREAM: {
+            uint32_t w[8];
+            for (int k = 0; k < 8; k++) w[k] = (uint32_t)in[i * 8 + k];
+            jk_pcg64 e = jk_pcg_seed(w);
+            for (uint64_t k = 0; k < aux; k++) out[i * aux + k] = jk_pcg_next(e);
+            break;
+        }
+        case JK_OP_RUNIF_INDEX: out[i] = jk_runif_index(in[i], aux); break;
+        case JK_OP_RUNIF_DOUBLE: out[i] = jk_d2u(jk_runif_double(in[i])); break;
+        case JK_OP_CANONICAL: out[i] = jk_d2u(jk_canonical(in[i])); break;
+        case JK_OP_N_QUAL: out[i] = jk_n_qual(in[i]); break;
+        case JK_OP_LT_HALF: out[i] = jk_runif_lt_half(in[i]) ? 1 : 0; break;
+        case JK_OP_FRAG_START: out[i] = jk_frag_start(in[i], aux); break;
+        case JK_OP_LOG: out[i] = jk_d2u(jk_log(jk_u2d(in[i]))); break;
+        case JK_OP_SQRT: out[i] = jk_d2u(jk_sqrt(jk_u2d(in[i]))); break;
+        case JK_OP_GAMMA_STREAM: {
+            uint32_t w[8];
+            for (int k = 0; k < 8; k++) w[k] = (uint32_t)in[i * 8 + k];
+            EvalRng r; r.e = jk_pcg_seed(w);
+            jk_gamma_state st; st.saved = 0; st.saved_available = 0;
+            for (uint64_t k = 0; k < aux; k++) out[i * aux + k] = jk_d2u(jk_gamma(gp, st, r));
+            break;
+        }
+        default: break;
+    }
+}
+
+__global__ void eval_kernel(int what, const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out, jk_gamma_param gp) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) eval_one(what, in, i, aux, out, gp);
+}
+
+static jk_gamma_param eval_gamma_param() {
+    jk_gamma_param gp;
+    gp.a1 = g_eval_shape - 1.0 / 3.0;
+    gp.a2 = 1.0 / std::sqrt(9.0 * gp.a1);
+    gp.beta = g_eval_scale;
+    return gp;
+}
+
+static void eval_sizes(int what, uint64_t n, uint64_t aux, uint64_t* n_in, uint64_t* n_out) {
+    const bool stream = (what == JK_OP_PCG_STREAM || what == JK_OP_GAMMA_STREAM);
+    *n_in = stream ? n * 8 : n;
+    *n_out = stream ? n * aux : n;
+}
+
+template <typename F>
+static int guarded(F f) {
+    try { f(); g_last_error.clear(); return JK_OK; }
+    catch (const Error& e) { g_last_error = e.what(); return e.code; }
+    catch (const std::bad_alloc&) { g_last_error = "out of host memory"; return JK_ERR_DEVICE; }
+    catch (const std::exception& e) { g_last_error = e.what(); return JK_ERR_ARG; }
+}
+
+}  // namespace jk
+
+extern "C" {
+
+const char* jk_last_error(void) { return g_last_error.c_str(); }
+const char* jk_version(void) { return "jackalope_hip 0.1 (gfx950)"; }
+
+int jk_illumina_ref_open(const jk_ref_genome* genome, const jk_illumina_args* args, jk_session** out) {
+    return guarded([&] {
+        if (!genome || !args || !out) throw Error(JK_ERR_ARG, "NULL argument");
+        std::unique_ptr<jk_session> s(new jk_session());
+        open_illumina_ref(*s, *genome, *args);
+        *out = s.release();
+    });
+}
+
+int jk_illumina_hap_open(const jk_hap_set*, const jk_illumina_args*, jk_session**) {
+    return guarded([&] { throw Error(JK_ERR_UNSUPPORTED, "haplotype sequencing is not implemented yet on the GPU path"); });
+}
+
+int jk_session_generate(jk_session* s) {
+    return guarded([&] { if (!s) throw Error(JK_ERR_ARG, "NULL session"); launch_generate(*s); });
+}
+
+int jk_session_sizes(const jk_session* s, uint64_t bytes[2], uint64_t* reads, uint32_t* n_ends) {
+    return guarded([&] {
+        if (!s || !s->generated) throw Error(JK_ERR_ARG, "session has not generated yet");
+        if (bytes) { bytes[0] = s->bytes[0]; bytes[1] = s->bytes[1]; }
+        if (reads) *reads = s->reads_made;
+        if (n_ends) *n_ends = s->n_ends;
+    });
+}
+
+int jk_session_device_ptr(const jk_session* s, uint32_t end, const void** dptr) {
+    return guarded([&] {
+        if (!s || !s->generated || end >= s->n_ends || !dptr) throw Error(JK_ERR_ARG, "bad session/end");
+        *dptr = s->d_out[end].p;
+    });
+}
+
+int jk_session_fetch(const jk_session* s, uint32_t end, void* dst, uint64_t cap) {
+    return guarded([&] {
+        if (!s || !s->generated || end >= s->n_ends) throw Error(JK_ERR_ARG, "bad session/end");
+        if (cap < s->bytes[end]) throw Error(JK_ERR_ARG, "destination too small");
+        JK_HIP(hipSetDevice(s->device));
+        if (s->bytes[end]) JK_HIP(hipMemcpy(dst, s->d_out[end].p, s->bytes[end], hipMemcpyDeviceToHost));
+    });
+}
+
+int jk_session_write(const jk_session* s) {
+    return guarded([&] { if (!s) throw Error(JK_ERR_ARG, "NULL session"); JK_HIP(hipSetDevice(s->device)); write_files(*s); });
+}
+
+int jk_session_timing(const jk_session* s, double ms[3]) {
+    return guarded([&] {
+        if (!s || !s->generated) throw Error(JK_ERR_ARG, "session has not generated yet");
+        ms[0] = s->ms[0]; ms[1] = s->ms[1]; ms[2] = s->ms[2];
+    });
+}
+
+uint64_t jk_session_seed_words_used(const jk_session* s) { return s ? s->seed_words_used : 0; }
+
+int jk_session_lane_bytes(const jk_session* s, uint32_t end, uint64_t* out, uint64_t n) {
+    return guarded([&] {
+        if (!s || !s->generated || end >= s->n_ends || n != s->n_shard) throw Error(JK_ERR_ARG, "bad session/end/count");
+        JK_HIP(hipSetDevice(s->device));
+        if (n) JK_HIP(hipMemcpy(out, s->d_lane_bytes[end].p, n * 8, hipMemcpyDeviceToHost));
+    });
+}
+
+void jk_session_close(jk_session* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    delete s;
+}
+
+int jk_illumina_ref(const jk_ref_genome* genome, const jk_illumina_args* args) {
+    jk_session* s = nullptr;
+    int rc = jk_illumina_ref_open(genome, args, &s);
+    if (rc == JK_OK) rc = jk_session_generate(s);
+    if (rc == JK_OK) rc = jk_session_write(s);
+    std::string keep = g_last_error;
+    jk_session_close(s);
+    g_last_error = keep;
+    return rc;
+}
+
+int jk_illumina_hap(const jk_hap_set* haps, const jk_illumina_args* args) {
+    jk_session* s = nullptr;
+    int rc = jk_illumina_hap_open(haps, args, &s);
+    if (rc == JK_OK) rc = jk_session_generate(s);
+    if (rc == JK_OK) rc = jk_session_write(s);
+    std::string keep = g_last_error;
+    jk_session_close(s);
+    g_last_error = keep;
+    return rc;
+}
+
+void jk_split_int(uint64_t x, uint64_t n, uint64_t* out) {
+    std::vector<uint64_t> v = split_int(x, n);
+    for (uint64_t i = 0; i < n; i++) out[i] = v[i];
+}
+
+int jk_reads_per_group(uint64_t n_reads, const double* probs, uint64_t n, jk_seed_source* seeds, uint64_t* out) {
+    return guarded([&] {
+        if (!seeds) throw Error(JK_ERR_ARG, "NULL seeds");
+        SeedReader r{*seeds};
+        std::vector<uint64_t> v = reads_per_group(n_reads, std::vector<double>(probs, probs + n), r);
+        for (uint64_t i = 0; i < n; i++) out[i] = v[i];
+        if (seeds->words) { seeds->words += r.pos; seeds->n_words -= r.pos; }
+    });
+}
+
+void jk_alias_build(const double* probs, uint64_t n, double* Prob, uint64_t* Alias) {
+    AliasTable t = alias_build(std::vector<double>(probs, probs + n));
+    for (uint64_t i = 0; i < n; i++) { Prob[i] = t.prob[i]; Alias[i] = t.alias[i]; }
+}
+
+int jk_hap_chrom_full(const jk_hap_set*, uint64_t, uint64_t, char*, uint64_t) {
+    return guarded([&] { throw Error(JK_ERR_UNSUPPORTED, "not implemented yet"); });
+}
+
+void jk_eval_set_gamma(double shape, double scale) { g_eval_shape = shape; g_eval_scale = scale; }
+
+int jk_host_eval(int what, const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out) {
+    return guarded([&] {
+        const jk_gamma_param gp = eval_gamma_param();
+        for (uint64_t i = 0; i < n; i++) eval_one(what, in, i, aux, out, gp);
+    });
+}
+
+int jk_dev_eval(int device, int what, const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out) {
+    return guarded([&] {
+        JK_HIP(hipSetDevice(device));
+        uint64_t n_in, n_out;
+        eval_sizes(what, n, aux, &n_in, &n_out);
+        DevBuf din, dout;
+        din.alloc(n_in * 8); dout.alloc(n_out * 8);
+        JK_HIP(hipMemcpy(din.p, in, n_in * 8, hipMemcpyHostToDevice));
+        const uint32_t block = 256;
+        const uint32_t grid = (uint32_t)((n + block - 1) / block);
+        hipLaunchKernelGGL(eval_kernel, dim3(grid ? grid : 1), dim3(block), 0, 0, what, din.as<uint64_t>(), n, aux, dout.as<uint64_t>(), eval_gamma_param());
+        JK_HIP(hipGetLastError());
+        JK_HIP(hipDeviceSynchronize());
+        JK_HIP(hipMemcpy(out, dout.p, n_out * 8, hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+// jk_host.h -- host-side set-up logic of the read-generation path (C++; no device code).
+//
+// Mirrors, for the GPU driver, what the reference does on the calling thread before its OpenMP
+// region: read quotas (split_int, src/util.h:245-258), seed consumption order
+// (mt_seeds then add_n_reads, src/hts.h:339,349-353), per-group binomial quotas (reads_per_group,
+// src/hts.h:58-103), Vose alias tables (AliasSampler::construct, src/alias_sampler.h:68-106) and
+// the quality -> mismatch-probability map (src/hts_illumina.h:182-187).  It then turns every
+// floating-point comparison the per-read loop makes against a fixed probability into an exact
+// 64-bit integer threshold on the raw pcg64 output (see jk_threshold_*), which is what the kernels
+// consume.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <deque>
+#include <numeric>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/jackalope_hip.h"
+#include "jk_math.h"
+
+namespace jk {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// ---- seed words -------------------------------------------------------------------------------
+struct SeedReader {
+    jk_seed_source src;
+    uint64_t pos = 0;      // words consumed
+    void take8(uint32_t* out) {
+        if (src.words) {
+            if (pos + 8 > src.n_words) throw Error(JK_ERR_SEEDS, "seed source exhausted: the path needs more 32-bit sub-seed words than were supplied");
+            for (int i = 0; i < 8; i++) out[i] = src.words[pos + i];
+        } else if (src.fn) {
+            if (src.fn(src.user, out) != 0) throw Error(JK_ERR_SEEDS, "seed callback failed");
+        } else {
+            throw Error(JK_ERR_SEEDS, "no seed source given (args.seeds)");
+        }
+        pos += 8;
+    }
+};
+
+// pcg64 as a C++ UniformRandomBitGenerator, for libstdc++'s binomial_distribution on the host.
+struct HostPcg {
+    typedef uint64_t result_type;
+    jk_pcg64 e;
+    static constexpr uint64_t min() { return 0; }
+    static constexpr uint64_t max() { return ~uint64_t(0); }
+    uint64_t operator()() { return jk_pcg_next(e); }
+};
+
+inline std::vector<uint64_t> split_int(uint64_t x, uint64_t n) {
+    std::vector<uint64_t> out(n, x / n);
+    uint64_t extra = x - n * (x / n);          // the first `extra` chunks get one more
+    for (uint64_t i = 0; i < extra; i++) out[i]++;
+    return out;
+}
+
+// Sequential conditional binomials over groups (reference: src/hts.h:58-103).  Consumes 8 seed words
+// whenever n_reads > 0 and there is at least one group, even when no binomial is then drawn.
+inline std::vector<uint64_t> reads_per_group(uint64_t n_reads, std::vector<double> probs, SeedReader& seeds) {
+    const size_t G = probs.size();
+    std::vector<uint64_t> out(G, 0);
+    if (n_reads == 0 || G == 0) return out;
+    uint32_t w[8];
+    seeds.take8(w);
+    HostPcg eng{jk_pcg_seed(w)};
+    double total = std::accumulate(probs.begin(), probs.end(), 0.0);
+    for (double& p : probs) p /= total;
+    std::binomial_distribution<uint64_t> binom(n_reads, 0.5);
+    for (size_t g = 0; g + 1 < G; g++) {
+        if (probs[g] >= 1) { out[g] = n_reads; return out; }
+        if (probs[g] == 0) continue;
+        binom.param(std::binomial_distribution<uint64_t>::param_type(n_reads, probs[g]));
+        out[g] = binom(eng);
+        n_reads -= out[g];
+        if (n_reads == 0) break;
+        const double rest = 1 - probs[g];
+        for (size_t j = g + 1; j < G; j++) probs[j] /= rest;
+    }
+    out[G - 1] = n_reads;
+    return out;
+}
+
+// ---- alias tables -----------------------------------------------------------------------------
+// Vose's method with FIFO small/large queues, normalisation p /= accu(p); p *= n where accu is
+// Armadillo's two-accumulator sum (the reference links RcppArmadillo; src/alias_sampler.h:70-71).
+struct AliasTable {
+    std::vector<double> prob;
+    std::vector<uint64_t> alias;
+};
+inline AliasTable alias_build(std::vector<double> p) {
+    const uint64_t n = p.size();
+    AliasTable t;
+    t.prob.assign(n, 0.0);
+    t.alias.assign(n, 0);
+    double s0 = 0, s1 = 0;
+    uint64_t i = 0;
+    for (; i + 1 < n; i += 2) { s0 += p[i]; s1 += p[i + 1]; }
+    if (i < n) s0 += p[i];
+    const double total = s0 + s1;
+    for (double& v : p) v /= total;
+    for (double& v : p) v *= static_cast<double>(n);
+    std::deque<uint64_t> small, large;
+    for (uint64_t k = 0; k < n; k++) (p[k] < 1 ? small : large).push_back(k);
+    while (!small.empty() && !large.empty()) {
+        const uint64_t l = small.front(), g = large.front();
+        small.pop_front(); large.pop_front();
+        t.prob[l] = p[l];
+        t.alias[l] = g;
+        p[g] = (p[g] + p[l]) - 1;
+        (p[g] < 1 ? small : large).push_back(g);
+    }
+    for (uint64_t g : large) t.prob[g] = 1;
+    for (uint64_t l : small) t.prob[l] = 1;
+    return t;
+}
+
+// ---- exact integer thresholds -----------------------------------------------------------------
+// u(x) = (double)runif_01 for raw engine output x is monotone non-decreasing in x, so for a fixed
+// double c the sets {x : u(x) < c} and {x : u(x) <= c} are prefixes [0, th).  `all` marks th = 2^64.
+struct Threshold { uint64_t th; bool all; };
+
+template <typename Pred>   // pred(x) true on a prefix of [0, 2^64)
+inline Threshold prefix_end(Pred pred) {
+    if (!pred(0)) return {0, false};
+    if (pred(~uint64_t(0))) return {0, true};
+    uint64_t lo = 0, hi = ~uint64_t(0);         // pred(lo) true, pred(hi) false
+    while (hi - lo > 1) {
+        uint64_t mid = lo + (hi - lo) / 2;
+        if (pred(mid)) lo = mid; else hi = mid;
+    }
+    return {hi, false};
+}
+inline Threshold threshold_lt(double c) { return prefix_end([c](uint64_t x) { return jk_runif_double(x) < c; }); }
+inline Threshold threshold_le(double c) { return prefix_end([c](uint64_t x) { return jk_runif_double(x) <= c; }); }
+
+// ---- Illumina error-model tables, flattened for the kernel ------------------------------------
+struct IlluminaTables {
+    uint32_t read_length = 0, n_ends = 0;
+    std::vector<uint32_t> info;     // [end][nt][pos] : first entry (24 bits) | n entries (8 bits)
+    std::vector<uint64_t> thresh;   // per entry: draw x2 picks the entry itself iff x2 < thresh
+    std::vector<uint16_t> quals;    // per entry: quality if picked | quality of its alias << 8
+    std::vector<uint64_t> mm_thresh;  // [256] : mismatch iff x3 < mm_thresh[q]  (qual_prob_map, hts_illumina.h:182-187)
+};
+
+inline void add_profile(IlluminaTables& T, const jk_illumina_profile& pr) {
+    const uint32_t L = pr.read_length;
+    if (!pr.n_quals || !pr.probs || !pr.quals) throw Error(JK_ERR_ARG, "profile arrays must not be NULL");
+    uint64_t off = 0;
+    for (uint32_t nt = 0; nt < 4; nt++) {
+        for (uint32_t pos = 0; pos < L; pos++) {
+            const uint32_t k = pr.n_quals[nt * L + pos];
+            if (k == 0 || k > 255) throw Error(JK_ERR_ARG, "each profile position needs between 1 and 255 qualities");
+            std::vector<double> p(pr.probs + off, pr.probs + off + k);
+            AliasTable at = alias_build(p);
+            const uint64_t first = T.thresh.size();
+            if (first + k >= (1u << 24)) throw Error(JK_ERR_UNSUPPORTED, "quality profile too large");
+            T.info.push_back(static_cast<uint32_t>(first) | (k << 24));
+            for (uint32_t i = 0; i < k; i++) {
+                Threshold th = threshold_lt(at.prob[i]);
+                const uint8_t q_self = pr.quals[off + i];
+                // when every draw picks the entry itself, make the alias point at it too
+                const uint8_t q_alias = th.all ? q_self : pr.quals[off + at.alias[i]];
+                T.thresh.push_back(th.all ? ~uint64_t(0) : th.th);
+                T.quals.push_back(static_cast<uint16_t>(q_self | (q_alias << 8)));
+            }
+            off += k;
+        }
+    }
+}
+
+inline IlluminaTables build_illumina_tables(const jk_illumina_args& a) {
+    IlluminaTables T;
+    T.read_length = a.profile1.read_length;
+    T.n_ends = a.paired ? 2 : 1;
+    if (T.read_length == 0) throw Error(JK_ERR_ARG, "read length must be > 0");
+    if (a.paired && a.profile2.read_length != a.profile1.read_length)
+        throw Error(JK_ERR_ARG, "In IlluminaOneGenome constr., read lengths for R1 and R2 don't match.");
+    add_profile(T, a.profile1);
+    if (a.paired) add_profile(T, a.profile2);
+    T.mm_thresh.assign(256, 0);
+    for (uint32_t q = 0; q < 256; q++) {
+        const double prob = (q == 0) ? 1.0 : std::pow(10, static_cast<double>(q) / -10.0);
+        Threshold th = threshold_lt(prob);
+        T.mm_thresh[q] = th.all ? ~uint64_t(0) : th.th;
+    }
+    return T;
+}
+
+}  // namespace jk

@@ -1,0 +1,463 @@
+// jk_illumina_kernel.h -- the Illumina per-read inner loop as a CDNA4 (gfx950) HIP kernel.
+//
+// One GPU thread = one "lane" = one OpenMP thread of the reference's driver
+// (write_reads_one_filetype_, /root/reference/src/hts.h:357-417): its own pcg64, its own read
+// quota, its own per-chromosome quotas, its own gamma state.  A lane runs the reference's
+// create_reads loop (src/hts.h:254-280) to completion and appends FASTQ text to its private "pool"
+// region in HBM (the analogue of ReadWriterOneThread::fastq_pools); a scan + compaction pass then
+// lays the pools out lane-major, which is the file order.
+//
+// What stays converged: every lane of a wave is in the same phase (fragment draw -> indel draws for
+// R1,R2 -> strand -> per-base quality/mismatch draws -> duplicate draw) at the same time; the rare
+// data-dependent extras (gamma rejections, indel events, mismatches, 'N' bases) are short divergent
+// branches.  The kernel is bound by the 128-bit pcg64 multiply (about 1200 draws per read pair),
+// not by HBM: per pair it reads 300 reference bytes and writes ~660 FASTQ bytes.
+//
+// Memory plan per workgroup: the ART quality tables (alias thresholds as exact u64 cut points on
+// the raw pcg output, qualities, mismatch cut points) are staged once into LDS (97.5 KB for the
+// HiSeq 2500 / 150 bp pair of profiles -> one 1024-thread workgroup per CU, 4 waves per SIMD);
+// profiles that do not fit in LDS are read through L2 instead (template parameter).
+#pragma once
+#include "jk_math.h"
+
+namespace jk {
+
+constexpr int JK_MAX_BARCODE = 32;
+constexpr int JK_MAX_EVW = 16;         // 64-bit words of indel-event bitmaps per read end (positions < 1024)
+
+// error bits reported through IlluminaKernelParams::err
+enum : uint32_t {
+    JK_KERR_TOO_MANY_DELETIONS = 1u,   // a read end needed more source positions than the event bitmaps hold
+    JK_KERR_POOL_OVERFLOW = 2u,        // internal: a lane wrote past its pool region
+};
+
+struct GenomeDev {
+    const uint8_t* seq;          // all chromosomes, 1 byte per base as given, 64-B padded
+    const uint64_t* chrom_off;   // [n_chroms] byte offset of chromosome in seq
+    const uint64_t* chrom_len;   // [n_chroms]
+    const uint8_t* hdr_blob;     // "@<genome>-<chrom>-" per chromosome
+    const uint32_t* hdr_off;     // [n_chroms + 1]
+    uint32_t n_chroms;
+};
+
+struct IlluminaKernelParams {
+    GenomeDev g;
+    // lanes of this launch
+    uint32_t n_lanes;
+    const uint32_t* seeds;       // [n_lanes * 8] sub-seed words
+    const uint64_t* lane_reads;  // [n_lanes] read quota (all ends)
+    const uint32_t* chrom_reads; // per-chromosome read quotas, chromosome-major: [ci * chrom_stride + lane]
+    uint32_t chrom_stride;
+    const uint64_t* pool_off;    // [n_lanes + 1] byte offset of each lane's pool region (same for every end)
+    uint8_t* pool[2];            // pool buffers, one per read end
+    uint64_t* lane_bytes[2];     // out: bytes written per lane and end
+    uint64_t* lane_made;         // out: reads made per lane
+    uint64_t* evw;               // scratch: [n_ends][4 planes][ev_words][n_lanes] indel bitmaps
+    uint32_t* err;
+    // model
+    uint32_t read_len, n_ends, paired, matepair;
+    uint32_t ev_words;
+    uint64_t frag_min, frag_max;
+    jk_gamma_param gp;
+    uint64_t th_match[2], th_del[2];   // draw x: x >= th_match -> match; else x >= th_del -> deletion; else insertion
+    uint32_t never_match[2], never_del[2];
+    uint64_t th_dup; uint32_t dup_all;
+    uint64_t pool_size;
+    uint32_t bc_len; uint8_t barcode[JK_MAX_BARCODE];
+    // tables (global copies; staged to LDS when LDS_TAB)
+    const uint32_t* info; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm_thresh;
+    uint32_t n_info, n_entries;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Byte appender into a lane's pool region.  Bytes are gathered into a 32-bit word and stored
+// when the word is complete; the first (partial) word of a stream that starts mid-word is written
+// byte by byte because its low bytes belong to whoever wrote before.
+// ---------------------------------------------------------------------------------------------
+struct OutStream {
+    uint8_t* p;        // address of the next byte
+    uint32_t w;        // bytes gathered for the current word
+    uint32_t head;     // 1 while the current word started mid-word
+};
+
+__device__ __forceinline__ void os_begin(OutStream& s, uint8_t* p) {
+    s.p = p; s.w = 0; s.head = (((uintptr_t)p) & 3u) ? 1u : 0u;
+}
+__device__ __forceinline__ void os_put(OutStream& s, uint32_t byte) {
+    const uint32_t k = (uint32_t)((uintptr_t)s.p) & 3u;
+    if (s.head) {
+        *s.p = (uint8_t)byte;
+        if (k == 3u) s.head = 0;
+    } else {
+        s.w |= byte << (8u * k);
+        if (k == 3u) { *reinterpret_cast<uint32_t*>(s.p - 3) = s.w; s.w = 0; }
+    }
+    s.p++;
+}
+// write out whatever is pending in the current word (as bytes); the stream can be abandoned after
+__device__ __forceinline__ void os_flush(OutStream& s) {
+    const uint32_t k = (uint32_t)((uintptr_t)s.p) & 3u;
+    if (!s.head) {
+        for (uint32_t j = 0; j < k; j++) *(s.p - k + j) = (uint8_t)(s.w >> (8u * j));
+    }
+    s.w = 0;
+    s.head = k ? 1u : 0u;     // if anything more is appended it continues this (already written) word
+}
+
+struct LaneRng {
+    jk_pcg64 e;
+    __device__ __forceinline__ uint64_t operator()() { return jk_pcg_next(e); }
+};
+
+__device__ __forceinline__ uint32_t nt_index(uint32_t c) {
+    // T0 C1 A2 G3, anything else 4 (sequencer::nt_map, src/hts.h:36-44)
+    return c == 'T' ? 0u : c == 'C' ? 1u : c == 'A' ? 2u : c == 'G' ? 3u : 4u;
+}
+__device__ __forceinline__ uint32_t cmp_base(uint32_t c) {
+    // str_manip::cmp_map (src/str_manip.h:58-72): T<->A, C<->G, N->N, everything else -> 0
+    return c == 'T' ? 'A' : c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'N' ? 'N' : 0u;
+}
+
+// tables either in LDS (Tab::lds = true) or global
+struct TabPtrs {
+    const uint32_t* info; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm;
+};
+
+template <bool LDS_TAB, uint32_t NE>      // NE = number of read ends (1 single-end, 2 paired)
+__global__ void __launch_bounds__(1024)
+illumina_ref_kernel(IlluminaKernelParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    TabPtrs T;
+    if (LDS_TAB) {
+        uint64_t* s_thresh = reinterpret_cast<uint64_t*>(smem);
+        uint64_t* s_mm = s_thresh + P.n_entries;
+        uint32_t* s_info = reinterpret_cast<uint32_t*>(s_mm + 256);
+        uint16_t* s_quals = reinterpret_cast<uint16_t*>(s_info + P.n_info);
+        for (uint32_t i = threadIdx.x; i < P.n_entries; i += blockDim.x) { s_thresh[i] = P.thresh[i]; s_quals[i] = P.quals[i]; }
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_mm[i] = P.mm_thresh[i];
+        for (uint32_t i = threadIdx.x; i < P.n_info; i += blockDim.x) s_info[i] = P.info[i];
+        __syncthreads();
+        T.info = s_info; T.thresh = s_thresh; T.quals = s_quals; T.mm = s_mm;
+    } else {
+        T.info = P.info; T.thresh = P.thresh; T.quals = P.quals; T.mm = P.mm_thresh;
+    }
+
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= P.n_lanes) return;
+
+    LaneRng rng;
+    rng.e = jk_pcg_seed(P.seeds + (size_t)lane * 8);
+    jk_gamma_state gst; gst.saved = 0.0; gst.saved_available = 0;
+
+    const uint32_t L = P.read_len, bc = P.bc_len;
+    const uint64_t quota = P.lane_reads[lane];
+    uint64_t made = 0, in_pool = 0;
+
+    // chromosome cursor: the reference rescans from chromosome 0 for the first non-zero quota
+    // (src/hts_illumina.cpp:199-200); quotas only ever decrease, so a monotone cursor is the same.
+    uint32_t ci = 0;
+    uint64_t ccnt = P.g.n_chroms ? P.chrom_reads[lane] : 0;
+
+    uint8_t* const base0 = P.pool[0] + P.pool_off[lane];
+    uint8_t* const base1 = NE > 1 ? P.pool[1] + P.pool_off[lane] : nullptr;
+    OutStream os[2];
+    os_begin(os[0], base0);
+    os_begin(os[1], base1);     // unused when NE == 1
+
+    uint64_t frag_len = 0, frag_start = 0;
+    uint32_t err = 0;
+    const uint32_t W = P.ev_words;
+    const size_t ev_stride = (size_t)P.n_lanes;
+    // plane p of end r, word w  ->  evw[((r*4 + p) * W + w) * n_lanes + lane]; p: 0 ins, 1 del, 2/3 inserted base bits
+    auto evaddr = [&](uint32_t r, uint32_t p, uint32_t w) -> uint64_t* {
+        return P.evw + ((size_t)((r * 4 + p) * W + w)) * ev_stride + lane;
+    };
+
+    bool is_dup = false;     // next pair re-reads the current fragment (re_read)
+    while (made < quota) {
+        if (!is_dup) {
+            // ---- chrom_indels_frag: chromosome, fragment length, fragment start (hts_illumina.cpp:192-217)
+            while (ci < P.g.n_chroms && ccnt == 0) { ci++; if (ci < P.g.n_chroms) ccnt = P.chrom_reads[(size_t)ci * P.chrom_stride + lane]; }
+            if (ci >= P.g.n_chroms) { made = quota; break; }         // `finished`
+            const uint64_t chrom_len = P.g.chrom_len[ci];
+            double gl = jk_gamma(P.gp, gst, rng);
+            frag_len = (uint64_t)gl;
+            if (frag_len < P.frag_min) frag_len = P.frag_min;
+            if (frag_len > P.frag_max) frag_len = P.frag_max;
+            if (frag_len >= chrom_len) { frag_len = chrom_len; frag_start = 0; }
+            else frag_start = jk_frag_start(rng(), chrom_len - frag_len + 1);
+        }
+        // ---- sample_indels + adjust_chrom_spaces (hts_illumina.cpp:117-184)
+        uint32_t space[2], out_len[2], evmask[2];   // evmask: bit w set = word w of (ins|del) non-zero
+#pragma unroll
+        for (uint32_t r = 0; r < NE; r++) {
+            uint64_t frag_pos = 0; uint32_t len_now = 0, n_ins = 0, n_del = 0, em = 0;
+            uint64_t iw = 0, dw = 0;
+            const uint64_t thm = P.th_match[r], thd = P.th_del[r];
+            const bool nm = P.never_match[r], nd = P.never_del[r];
+            while (len_now < L && frag_pos < frag_len) {
+                if (frag_pos >= (uint64_t)W * 64) { err |= JK_KERR_TOO_MANY_DELETIONS; break; }
+                const uint64_t x = rng();
+                if (!nm && x >= thm) {
+                    len_now++;
+                } else if (!nd && x >= thd) {
+                    dw |= 1ULL << (frag_pos & 63); n_del++;
+                } else {
+                    if (len_now == L - 1) len_now++;
+                    else { iw |= 1ULL << (frag_pos & 63); n_ins++; len_now += 2; }
+                }
+                frag_pos++;
+                if ((frag_pos & 63) == 0) {
+                    const uint32_t w = (uint32_t)(frag_pos >> 6) - 1;
+                    if (iw | dw) {
+                        if (w < W) { *evaddr(r, 0, w) = iw; *evaddr(r, 1, w) = dw; em |= 1u << w; }
+                        else err |= JK_KERR_TOO_MANY_DELETIONS;
+                        iw = 0; dw = 0;
+                    }
+                }
+            }
+            if (iw | dw) {
+                const uint32_t w = (uint32_t)(frag_pos >> 6);
+                if (w < W) { *evaddr(r, 0, w) = iw; *evaddr(r, 1, w) = dw; em |= 1u << w; }
+                else err |= JK_KERR_TOO_MANY_DELETIONS;
+            }
+            uint64_t sp = (uint64_t)L + n_del - n_ins;
+            if (sp > frag_len) sp = frag_len;
+            space[r] = (uint32_t)sp;
+            out_len[r] = (uint32_t)sp - n_del + n_ins;
+            evmask[r] = em;
+        }
+        if (err) break;
+
+        // ---- append_pools (hts_illumina.cpp:339-409)
+        bool reverse = jk_runif_lt_half(rng());
+#pragma unroll
+        for (uint32_t i = 0; i < NE; i++) {
+            const uint32_t sp = space[i], n_out = out_len[i], em = evmask[i];
+            const uint64_t cspace = (uint64_t)sp - bc;
+            uint64_t start;
+            if ((!P.matepair && !reverse) || (P.matepair && reverse)) start = frag_start;
+            else start = frag_start + frag_len - cspace;
+
+            // inserted bases are drawn first, right to left (hts_illumina.h:213-225)
+            if (em) {
+                for (int w = (int)W - 1; w >= 0; w--) {
+                    if (!((em >> w) & 1u)) continue;
+                    uint64_t iw = *evaddr(i, 0, w), b0 = 0, b1 = 0;
+                    uint64_t rest = iw;
+                    while (rest) {
+                        const int bit = 63 - jk_clz64(rest);
+                        rest &= ~(1ULL << bit);
+                        const uint64_t b = jk_runif_index(rng(), 4) & 3u;   // index 4 needs x == 2^64-1
+                        b0 |= (b & 1u) << bit; b1 |= (b >> 1) << bit;
+                    }
+                    *evaddr(i, 2, w) = b0; *evaddr(i, 3, w) = b1;
+                }
+            }
+
+            // ---- FASTQ id line (fill_fq_lines, hts_illumina.cpp:286-312)
+            OutStream& o = os[i];
+            {
+                const uint32_t h0 = P.g.hdr_off[ci], h1 = P.g.hdr_off[ci + 1];
+                for (uint32_t h = h0; h < h1; h++) os_put(o, P.g.hdr_blob[h]);
+                uint64_t v = start, packed_lo = 0, packed_hi = 0; uint32_t nd = 0;
+                do {   // decimal digits, most significant ends up in the lowest nibble
+                    const uint64_t q = v / 10, d = v - q * 10;
+                    packed_hi = (packed_hi << 4) | (packed_lo >> 60);
+                    packed_lo = (packed_lo << 4) | d;
+                    v = q; nd++;
+                } while (v);
+                for (uint32_t d = 0; d < nd; d++) {
+                    os_put(o, '0' + (uint32_t)(packed_lo & 15u));
+                    packed_lo = (packed_lo >> 4) | (packed_hi << 60); packed_hi >>= 4;
+                }
+                os_put(o, '-');
+                os_put(o, reverse ? 'R' : 'F');
+                if (P.paired) { os_put(o, '/'); os_put(o, '1' + i); }
+                os_put(o, '\n');
+            }
+            // the quality line is produced in the same pass as the bases, by its own stream that
+            // starts right after the bases with "\n+\n"
+            OutStream oq;
+            os_begin(oq, o.p + n_out);
+            os_put(oq, '\n'); os_put(oq, '+'); os_put(oq, '\n');
+
+            // ---- bases + qualities (fill_read / rev_comp / fill_read_qual)
+            const uint8_t* chrom = P.g.seq + P.g.chrom_off[ci];
+            // source position pp of the (pre-indel) read: pp < bc barcode; else forward chrom[start + pp - bc],
+            // reverse: complement of chrom[start + sp - 1 - pp]
+            uint64_t gpos = reverse ? (start + sp - 1 - bc) : start;
+            uint32_t pp = 0;
+            uint64_t iw = 0, dw = 0, b0w = 0, b1w = 0;
+            if (em & 1u) { iw = *evaddr(i, 0, 0); dw = *evaddr(i, 1, 0); b0w = *evaddr(i, 2, 0); b1w = *evaddr(i, 3, 0); }
+            bool pending = false; uint32_t pend_base = 0;
+            const uint32_t tab_base = i * 4u * L;
+            for (uint32_t op = 0; op < n_out; op++) {
+                uint32_t c;
+                if (pending) {
+                    c = (pend_base == 0 ? 'T' : pend_base == 1 ? 'C' : pend_base == 2 ? 'A' : 'G');
+                    pending = false;
+                } else {
+                    for (;;) {
+                        const uint32_t bit = pp & 63u;
+                        const bool deleted = em && ((dw >> bit) & 1ULL);
+                        if (!deleted) {
+                            if (pp < bc) c = P.barcode[pp];
+                            else { c = chrom[gpos]; if (reverse) c = cmp_base(c); }
+                            if (em && ((iw >> bit) & 1ULL)) {
+                                pending = true;
+                                pend_base = (uint32_t)((b0w >> bit) & 1ULL) | ((uint32_t)((b1w >> bit) & 1ULL) << 1);
+                            }
+                        }
+                        if (pp >= bc) gpos += reverse ? (uint64_t)-1 : 1;
+                        pp++;
+                        if (em && (pp & 63u) == 0) {
+                            const uint32_t w = pp >> 6;
+                            if (w < W && ((em >> w) & 1u)) { iw = *evaddr(i, 0, w); dw = *evaddr(i, 1, w); b0w = *evaddr(i, 2, w); b1w = *evaddr(i, 3, w); }
+                            else { iw = dw = b0w = b1w = 0; }
+                        }
+                        if (!deleted) break;
+                    }
+                }
+                const uint32_t nt = nt_index(c);
+                uint32_t q;
+                if (nt > 3) {
+                    q = jk_n_qual(rng());
+                    c = 'N';
+                } else {
+                    const uint32_t inf = T.info[tab_base + nt * L + op];
+                    const uint32_t first = inf & 0xffffffu, n = inf >> 24;
+                    const uint32_t e = first + (uint32_t)jk_runif_index(rng(), n);
+                    const uint64_t x2 = rng();
+                    const uint32_t qq = T.quals[e];
+                    const uint32_t k = (x2 < T.thresh[e]) ? (qq & 0xffu) : (qq >> 8);
+                    q = (k + 33u) & 0xffu;
+                    const uint64_t x3 = rng();
+                    if (x3 < T.mm[k]) {
+                        const uint32_t m = (uint32_t)jk_runif_index(rng(), 3);
+                        // mm_nucleos = {"CAG","TAG","TCG","TCA"} (src/hts.h:46)
+                        const uint32_t packed = nt == 0 ? 0x474143u : nt == 1 ? 0x474154u : nt == 2 ? 0x474354u : 0x414354u;
+                        c = (m < 3) ? ((packed >> (8u * m)) & 0xffu) : 0u;
+                    }
+                }
+                os_put(o, c);
+                os_put(oq, q);
+            }
+            os_put(oq, '\n');
+            os_flush(o);
+            o = oq;                    // the next record continues where the quality stream stopped
+            reverse = !reverse;
+        }
+        // quota bookkeeping (hts_illumina.cpp:404-406)
+        ccnt = (ccnt < NE) ? 0 : ccnt - NE;
+
+        // ---- ReadWriterOneThread::create_reads tail (src/hts.h:263-278)
+        made += NE; in_pool += NE;
+        const uint64_t xd = rng();
+        const bool dup = P.dup_all || xd < P.th_dup;
+        // the duplicate loop only continues while the pool has room and the quota is not met; a
+        // full pool (or met quota) is flushed, which on the GPU only resets the counter
+        if (dup && made < quota && in_pool < P.pool_size) {
+            is_dup = true;
+        } else {
+            is_dup = false;
+            if (in_pool >= P.pool_size || made >= quota) in_pool = 0;
+        }
+    }
+
+#pragma unroll
+    for (uint32_t i = 0; i < NE; i++) {
+        os_flush(os[i]);
+        const uint64_t nbytes = (uint64_t)(os[i].p - (i == 0 ? base0 : base1));
+        P.lane_bytes[i][lane] = nbytes;
+        if (nbytes > P.pool_off[lane + 1] - P.pool_off[lane]) err |= JK_KERR_POOL_OVERFLOW;
+    }
+    P.lane_made[lane] = made;
+    if (err) atomicOr(P.err, err);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pool compaction: lane-major FASTQ image.  One wave per lane copies that lane's pool region
+// (16-B aligned source) to its final offset (arbitrary alignment) in 16-B pieces.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
+                     const uint64_t* __restrict__ lane_bytes, const uint64_t* __restrict__ out_off,
+                     uint8_t* __restrict__ out, const uint64_t* __restrict__ out_base, uint32_t n_lanes) {
+    const uint32_t lane = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (lane >= n_lanes) return;
+    const uint32_t t = threadIdx.x & 63u;
+    const uint8_t* src = pool + pool_off[lane];
+    uint8_t* dst = out + out_base[0] + out_off[lane];
+    const uint64_t n = lane_bytes[lane];
+    const uint64_t n16 = n >> 4;
+    for (uint64_t c = t; c < n16; c += 64) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src + c * 16);
+        __builtin_memcpy(dst + c * 16, &v, 16);
+    }
+    const uint64_t tail = n16 << 4;
+    if (tail + t < n) dst[tail + t] = src[tail + t];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exclusive scan of per-lane byte counts (u64), three small kernels.
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 1024;
+
+__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t* total) {
+    __shared__ uint64_t wsum[SCAN_BLOCK / 64];
+    const uint32_t lid = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    uint64_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t o = __shfl_up(incl, d, 64);
+        if ((int)lid >= d) incl += o;
+    }
+    if (lid == 63) wsum[wid] = incl;
+    __syncthreads();
+    if (wid == 0) {
+        uint64_t s = lid < SCAN_BLOCK / 64 ? wsum[lid] : 0, si = s;
+        for (int d = 1; d < SCAN_BLOCK / 64; d <<= 1) {
+            uint64_t o = __shfl_up(si, d, 64);
+            if ((int)lid >= d) si += o;
+        }
+        if (lid < SCAN_BLOCK / 64) wsum[lid] = si - s;     // exclusive prefix of wave sums
+        if (lid == SCAN_BLOCK / 64 - 1) *total = si;
+    }
+    __syncthreads();
+    const uint64_t r = wsum[wid] + incl - v;
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_block_kernel(const uint64_t* in, uint64_t* out, uint64_t* block_sums, uint32_t n) {
+    __shared__ uint64_t total;
+    const uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const uint64_t v = i < n ? in[i] : 0;
+    const uint64_t ex = block_exclusive_scan(v, &total);
+    if (i < n) out[i] = ex;
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+// single block: exclusive scan of block sums in place; base[1] = base[0] + grand total (the running
+// byte offset of the next batch in the FASTQ image, kept on the device so no host sync is needed)
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_sums_kernel(uint64_t* block_sums, uint32_t nb, uint64_t* base) {
+    __shared__ uint64_t total;
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += SCAN_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = i < nb ? block_sums[i] : 0;
+        const uint64_t ex = block_exclusive_scan(v, &total);
+        if (i < nb) block_sums[i] = ex + carry;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) base[1] = base[0] + carry;
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) scan_add_kernel(uint64_t* out, const uint64_t* block_sums, uint32_t n) {
+    const uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    if (i < n) out[i] += block_sums[blockIdx.x];
+}
+
+}  // namespace jk

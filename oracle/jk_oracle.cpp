@@ -1,0 +1,898 @@
+// =====================================================================================
+// TEST INFRASTRUCTURE ONLY.  CPU restatement ("oracle") of jackalope's HTS read-generation
+// path.  Nothing under jackalope_amd/ may include, link or call this file: only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker.
+//
+// What it restates (reference = /root/reference, jackalope v1.1.6; file:line cited at each
+// function).  It deliberately keeps the reference's *arithmetic types*: x87 `long double`
+// for runif_01 (src/pcg.h:99-105) and libstdc++'s own std::gamma_distribution /
+// std::binomial_distribution (the reference calls exactly these: src/hts_illumina.h:301,
+// src/hts.h:69) driven by a restated pcg64.  It is therefore only meaningful on x86-64 with
+// libstdc++/glibc -- the platform the reference's bytes are defined on.
+//
+// Parity status: the pcg64 restatement is pinned against the reference's own PCG headers
+// (oracle/_ref/libref_pcg.so, built by oracle/Makefile from /root/reference/inst/include).
+// The rest of the reference path needs Rcpp, RcppArmadillo, RcppProgress and Rhtslib headers
+// that this image lacks, so it is unbuildable here; those parts of the oracle are pinned by
+// the reference's own known-answer tests (tests/testthat/test-sequencer.R:82-161,
+// tests/testthat/test-vcf_IO.R:14-90), restated in tests/.  No golden FASTQ exists in the
+// reference (its tests fix no seed), so byte-level parity of sampled quantities is
+// "parity unpinned" beyond those tests -- see DESIGN.md.
+//
+// Third-party arithmetic that is NOT under /root/reference and is restated from its published
+// algorithm: Armadillo `accu` (two interleaved accumulators, arrayops::accumulate; version
+// unpinned in DESCRIPTION:33) used at src/alias_sampler.h:70.
+// =====================================================================================
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <deque>
+#include <random>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include <algorithm>
+#include <numeric>
+
+namespace orc {
+
+typedef unsigned __int128 u128;
+typedef uint64_t u64;
+typedef int64_t s64;
+typedef unsigned char u8;   // reference: uint8 = uint_fast8_t = unsigned char on Linux (src/jackalope_types.h:26)
+
+// -------------------------------------------------------------------------------------
+// pcg64 = setseq_xsl_rr_128_64 (inst/include/pcg/pcg_random.hpp:1675).
+// engine ctor(state, stream): :471-477; bump :387-390; operator() post-advance for 128-bit
+// state (output_previous = false) :405-411; XSL-RR output :971-998; default 128-bit
+// multiplier :149-152; setseq increment = (stream << 1) | 1.
+// -------------------------------------------------------------------------------------
+struct Pcg64 {
+    typedef u64 result_type;
+    u128 state, inc;
+    static constexpr u64 min() { return 0; }
+    static constexpr u64 max() { return ~u64(0); }
+    static u128 mult() { return ((u128)2549297995355413924ULL << 64) | 4865540595714422341ULL; }
+    Pcg64() : state(0), inc(1) {}
+    Pcg64(u128 seed1, u128 seed2) {
+        inc = (seed2 << 1) | 1;
+        state = (seed1 + inc) * mult() + inc;
+    }
+    u64 operator()() {
+        state = state * mult() + inc;
+        u64 hi = (u64)(state >> 64), lo = (u64)state;
+        unsigned rot = (unsigned)(hi >> 58);
+        u64 x = hi ^ lo;
+        return (x >> rot) | (x << ((64 - rot) & 63));
+    }
+};
+
+// src/pcg.h:48-61 fill_seeds + :73-84 seeded_pcg(sub_seeds)
+static Pcg64 seeded_pcg(const uint32_t* w) {
+    u128 a = ((u128)w[0] << 32) + w[1];
+    u128 b = ((u128)w[2] << 32) + w[3];
+    u128 c = ((u128)w[4] << 32) + w[5];
+    u128 d = ((u128)w[6] << 32) + w[7];
+    return Pcg64((a << 64) + b, (c << 64) + d);
+}
+
+// src/pcg.h:21,99-101.  pcg::max64 is a long double holding 2^64-1; "+ 2" rounds to 2^64 in
+// the x87 64-bit significand, exactly as it does in the reference.
+static const long double MAX64 = static_cast<long double>(Pcg64::max());
+static inline long double runif_01(Pcg64& eng) {
+    return (static_cast<long double>(eng()) + 1) / (MAX64 + 2);
+}
+static inline long double runif_01_from(u64 x) {
+    return (static_cast<long double>(x) + 1) / (MAX64 + 2);
+}
+
+// Source of the 32-bit sub-seed words the reference pulls from R's RNG
+// (Rcpp::runif(8, 0, 4294967296) truncated; src/pcg.h:37-46,63-71).
+struct SeedSource {
+    const uint32_t* w; u64 n; u64 pos;
+    const uint32_t* take8() {
+        if (pos + 8 > n) throw std::runtime_error("oracle: seed words exhausted");
+        const uint32_t* r = w + pos; pos += 8; return r;
+    }
+};
+
+// -------------------------------------------------------------------------------------
+// AliasSampler (src/alias_sampler.h:36-106).  arma::accu restated as Armadillo's
+// arrayops::accumulate (pairwise-interleaved two accumulators); `p /= s; p *= n` element-wise.
+// -------------------------------------------------------------------------------------
+static double arma_accu(const std::vector<double>& v) {
+    double acc1 = 0, acc2 = 0;
+    size_t n = v.size(), j, i = 0;
+    for (j = 1; j < n; j += 2) { acc1 += v[i++]; acc2 += v[i++]; }
+    if ((j - 1) < n) acc1 += v[i];
+    return acc1 + acc2;
+}
+
+struct Alias {
+    std::vector<double> Prob;
+    std::vector<u64> Ali;
+    u64 n;
+    Alias() : n(0) {}
+    explicit Alias(std::vector<double> p) : Prob(p.size()), Ali(p.size()), n(p.size()) {
+        double s = arma_accu(p);
+        for (double& x : p) x /= s;
+        for (double& x : p) x *= static_cast<double>(n);
+        std::deque<u64> Small, Large;
+        for (u64 i = 0; i < n; i++) { if (p[i] < 1) Small.push_back(i); else Large.push_back(i); }
+        while (!Small.empty() && !Large.empty()) {
+            u64 l = Small.front(); Small.pop_front();
+            u64 g = Large.front(); Large.pop_front();
+            Prob[l] = p[l];
+            Ali[l] = g;
+            p[g] = (p[g] + p[l]) - 1;
+            if (p[g] < 1) Small.push_back(g); else Large.push_back(g);
+        }
+        while (!Large.empty()) { Prob[Large.front()] = 1; Large.pop_front(); }
+        while (!Small.empty()) { Prob[Small.front()] = 1; Small.pop_front(); }
+    }
+    // src/alias_sampler.h:53-60
+    u64 sample(Pcg64& eng) const {
+        u64 i = runif_01(eng) * n;
+        double u = runif_01(eng);
+        if (u < Prob[i]) return i;
+        return Ali[i];
+    }
+};
+
+// -------------------------------------------------------------------------------------
+// Tables used by the sequencers (src/hts.h:36-46, src/jackalope_types.h:36,
+// src/str_manip.h:58-72).
+// -------------------------------------------------------------------------------------
+static inline u8 nt_index(char c) {
+    switch (c) { case 'T': return 0; case 'C': return 1; case 'A': return 2; case 'G': return 3; default: return 4; }
+}
+static const char* const MM_NUCLEOS[5] = {"CAG", "TAG", "TCG", "TCA", "NNN"};
+static const std::string BASES = "TCAG";
+static inline char cmp_char(char c) {
+    switch (c) { case 'T': return 'A'; case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C';
+                 case 'N': return 'N'; default: return 0; }
+}
+// src/str_manip.h:214-229
+static void rev_comp(std::string& s) {
+    u64 n = s.size(), half = n / 2;
+    for (u64 j = 0; j < half; j++) {
+        char tmp = cmp_char(s[j]);
+        s[j] = cmp_char(s[n - j - 1]);
+        s[n - j - 1] = tmp;
+    }
+    if (n & 1ULL) s[half] = cmp_char(s[half]);
+}
+// src/str_manip.h:234-248 (first n chars only; PacBio)
+static void rev_comp_n(std::string& s, u64 n) {
+    u64 half = n / 2;
+    for (u64 j = 0; j < half; j++) {
+        char tmp = cmp_char(s[j]);
+        s[j] = cmp_char(s[n - j - 1]);
+        s[n - j - 1] = tmp;
+    }
+    if (n & 1ULL) s[half] = cmp_char(s[half]);
+}
+
+// src/util.h:245-258
+static std::vector<u64> split_int(u64 x, u64 n) {
+    std::vector<u64> out(n, x / n);
+    u64 sum = n * (x / n), i = 0;
+    while (sum < x) { out[i]++; i++; sum++; }
+    return out;
+}
+
+// src/hts.h:58-103.  A fresh engine is seeded from 8 sub-seed words whenever n_reads > 0 and
+// probs is non-empty, even if it is then never used (probs.size() == 1).
+static std::vector<u64> reads_per_group(u64 n_reads, std::vector<double> probs, SeedSource& seeds) {
+    std::vector<u64> out(probs.size(), 0);
+    if (n_reads == 0 || probs.size() == 0) return out;
+    Pcg64 eng = seeded_pcg(seeds.take8());
+    double sum_probs = std::accumulate(probs.begin(), probs.end(), 0.0);
+    for (double& p : probs) p /= sum_probs;
+    std::binomial_distribution<u64> distr(n_reads, 0.5);
+    for (u64 i = 0; i < (probs.size() - 1); i++) {
+        if (probs[i] >= 1) { out[i] = n_reads; return out; }
+        if (probs[i] == 0) continue;
+        distr.param(std::binomial_distribution<u64>::param_type(n_reads, probs[i]));
+        out[i] = distr(eng);
+        n_reads -= out[i];
+        if (n_reads == 0) break;
+        sum_probs = 1 - probs[i];
+        for (u64 j = i + 1; j < probs.size(); j++) probs[j] /= sum_probs;
+    }
+    out.back() = n_reads;
+    return out;
+}
+
+// -------------------------------------------------------------------------------------
+// Illumina quality/mismatch model: IllQualPos + IlluminaQualityError
+// (src/hts_illumina.h:93-277).
+// -------------------------------------------------------------------------------------
+struct Profile {              // one read end: [nt 0..3][pos][k]
+    std::vector<std::vector<std::vector<double>>> probs;
+    std::vector<std::vector<std::vector<u8>>> quals;
+};
+
+struct QualErr {
+    std::vector<std::vector<Alias>> samplers;        // [nt][pos]
+    std::vector<std::vector<std::vector<u8>>> quals;  // [nt][pos][k]
+    std::vector<double> qual_prob_map;
+    QualErr() {}
+    explicit QualErr(const Profile& pr) : quals(pr.quals) {
+        if (pr.probs.size() != 4 || pr.quals.size() != 4) throw std::runtime_error("profile must have 4 nucleotides");
+        u64 L = pr.probs[0].size();
+        u8 max_qual = 0;
+        samplers.resize(4);
+        for (int nt = 0; nt < 4; nt++) {
+            if (pr.probs[nt].size() != L || pr.quals[nt].size() != L) throw std::runtime_error("profile lengths differ");
+            for (u64 pos = 0; pos < L; pos++) samplers[nt].push_back(Alias(pr.probs[nt][pos]));
+            for (const auto& qv : pr.quals[nt]) {
+                u8 m = *std::max_element(qv.begin(), qv.end());
+                if (m > max_qual) max_qual = m;
+            }
+        }
+        // src/hts_illumina.h:182-187
+        qual_prob_map.push_back(1);
+        for (u64 q = 1; q < (static_cast<u64>(max_qual) + 1ULL); q++)
+            qual_prob_map.push_back(std::pow(10, static_cast<double>(q) / -10.0));
+    }
+
+    // src/hts_illumina.h:202-259
+    void fill_read_qual(std::string& read, std::string& qual, std::deque<u64>& insertions,
+                        std::deque<u64>& deletions, Pcg64& eng) const {
+        const u8 qual_start = static_cast<u8>('!');
+        u64 chrom_pos = read.size() - 1ULL;
+        while (!insertions.empty() || !deletions.empty()) {
+            if (!insertions.empty() && chrom_pos == insertions.back()) {
+                char c = BASES[static_cast<u64>(runif_01(eng) * 4.0)];
+                read.insert(chrom_pos + 1, 1, c);
+                insertions.pop_back();
+            } else if (!deletions.empty() && chrom_pos == deletions.back()) {
+                read.erase(chrom_pos, 1);
+                deletions.pop_back();
+            }
+            if (chrom_pos == 0) break;
+            chrom_pos--;
+        }
+        if (qual.size() != read.size()) qual.resize(read.size());
+        for (u64 pos = 0; pos < read.size(); pos++) {
+            char& nt = read[pos];
+            u8 nt_ind = nt_index(nt);
+            u8 qint;
+            if (nt_ind > 3) {
+                qint = runif_01(eng) * 10 + qual_start;
+                qual[pos] = static_cast<char>(qint);
+                nt = 'N';
+                continue;
+            }
+            u64 k = samplers[nt_ind][pos].sample(eng);
+            qint = quals[nt_ind][pos][k];
+            double mis_prob = qual_prob_map[qint];
+            qint += qual_start;
+            qual[pos] = static_cast<char>(qint);
+            double u = runif_01(eng);
+            if (u < mis_prob) {
+                const char* mm = MM_NUCLEOS[nt_ind];
+                nt = mm[static_cast<u64>(runif_01(eng) * 3.0)];
+            }
+        }
+    }
+};
+
+// -------------------------------------------------------------------------------------
+// Genome views.  A "genome" for the sequencer is a name plus named chromosome strings
+// (RefGenome: src/ref_classes.h:127-180; haplotype chromosomes are materialised by
+// HapChrom::get_chrom_full first, exactly as IlluminaHaplotypes::one_read does,
+// src/hts_illumina.cpp:527).
+// -------------------------------------------------------------------------------------
+struct Genome {
+    std::string name;
+    std::vector<std::string> chrom_names;
+    std::vector<const std::string*> chroms;   // may be filled lazily for haplotypes
+    std::vector<u64> chrom_sizes;
+};
+
+// src/ref_classes.h:102-116 / src/hts.h:109-130
+static void fill_read(const std::string& chrom, std::string& read, u64 read_start, u64 chrom_start, u64 n_to_add) {
+    if ((chrom_start + n_to_add - 1) >= chrom.size()) n_to_add = chrom.size() - chrom_start;
+    if (read.size() < n_to_add + read_start) read.resize(n_to_add + read_start, 'N');
+    for (u64 i = 0; i < n_to_add; i++) read[read_start + i] = chrom[chrom_start + i];
+}
+
+// src/hts_illumina.cpp:286-326
+static void fill_fq_lines(std::vector<char>& pool, const std::string& name, const std::string& chrom_name,
+                          const std::string& read, const std::string& qual, u64 i, u64 start, bool paired,
+                          bool& reverse) {
+    pool.push_back('@');
+    for (char c : name) pool.push_back(c);
+    pool.push_back('-');
+    for (char c : chrom_name) pool.push_back(c);
+    pool.push_back('-');
+    for (char c : std::to_string(start)) pool.push_back(c);
+    pool.push_back('-');
+    pool.push_back(reverse ? 'R' : 'F');
+    if (paired) { pool.push_back('/'); for (char c : std::to_string(i + 1)) pool.push_back(c); }
+    pool.push_back('\n');
+    for (char c : read) pool.push_back(c);
+    pool.push_back('\n'); pool.push_back('+'); pool.push_back('\n');
+    for (char c : qual) pool.push_back(c);
+    pool.push_back('\n');
+    reverse = !reverse;
+}
+
+// -------------------------------------------------------------------------------------
+// IlluminaOneGenome<T> (src/hts_illumina.h:293-497, src/hts_illumina.cpp:33-482).
+// One object per reference "thread" (= lane); the gamma distribution object (with libstdc++'s
+// saved normal deviate) lives inside it, as in the reference.
+// -------------------------------------------------------------------------------------
+struct IlluminaParams {
+    bool paired, matepair;
+    double shape, scale;
+    u64 frag_len_min, frag_len_max;
+    Profile prof[2];
+    double ins_prob[2], del_prob[2];
+};
+
+struct IlluminaOneGenome {
+    std::vector<QualErr> qual_errors;
+    std::gamma_distribution<double> frag_lengths;
+    std::vector<u64> chrom_reads;
+    const Genome* genome;
+    u64 read_length;
+    bool paired, matepair;
+    std::vector<double> ins_probs, del_probs;
+    std::vector<std::deque<u64>> insertions, deletions;
+    u64 frag_len_min, frag_len_max;
+    // IlluminaReadConstrInfo (src/hts_illumina.h:45-84)
+    u64 chrom_ind, frag_len, frag_start;
+    std::vector<std::string> reads, quals;
+    std::vector<u64> read_chrom_spaces;
+    std::string barcode;
+
+    IlluminaOneGenome(const Genome& g, const IlluminaParams& p, const std::string& barcode_)
+        : frag_lengths(p.shape, p.scale), genome(&g), read_length(p.prof[0].probs[0].size()),
+          paired(p.paired), matepair(p.paired ? p.matepair : false),
+          frag_len_min(p.frag_len_min), frag_len_max(p.frag_len_max),
+          chrom_ind(0), frag_len(0), frag_start(0), barcode(barcode_) {
+        u64 ne = paired ? 2 : 1;
+        if (paired && p.prof[0].probs[0].size() != p.prof[1].probs[0].size())
+            throw std::runtime_error("In IlluminaOneGenome constr., read lengths for R1 and R2 don't match.");
+        for (u64 r = 0; r < ne; r++) {
+            qual_errors.push_back(QualErr(p.prof[r]));
+            ins_probs.push_back(p.ins_prob[r]);
+            del_probs.push_back(p.del_prob[r]);
+        }
+        insertions.resize(ne); deletions.resize(ne);
+        reads.assign(ne, std::string(read_length, 'N'));
+        quals.assign(ne, std::string());
+        read_chrom_spaces.assign(ne, 0);
+    }
+
+    // src/hts_illumina.h:410-418
+    void add_n_reads(u64 n_reads, SeedSource& seeds) {
+        std::vector<double> probs_(genome->chrom_sizes.begin(), genome->chrom_sizes.end());
+        if (paired) n_reads /= 2;
+        chrom_reads = reads_per_group(n_reads, probs_, seeds);
+        if (paired) for (u64& r : chrom_reads) r *= 2;
+    }
+
+    // src/hts_illumina.cpp:117-150
+    void sample_indels(Pcg64& eng) {
+        for (u64 r = 0; r < insertions.size(); r++) {
+            u64 frag_pos = 0, length_now = 0;
+            std::deque<u64>& ins = insertions[r];
+            std::deque<u64>& del = deletions[r];
+            const double ins_prob = ins_probs[r], del_prob = del_probs[r];
+            ins.clear(); del.clear();
+            while (length_now < read_length && frag_pos < frag_len) {
+                double u = runif_01(eng);
+                if (u > (ins_prob + del_prob)) {
+                    length_now++;
+                } else if (u > ins_prob) {
+                    del.push_back(frag_pos);
+                } else {
+                    if (length_now == (read_length - 1)) length_now++;
+                    else { ins.push_back(frag_pos); length_now += 2; }
+                }
+                frag_pos++;
+            }
+        }
+    }
+    // src/hts_illumina.cpp:154-184
+    void adjust_chrom_spaces() {
+        for (u64 r = 0; r < insertions.size(); r++) {
+            s64 indel_effect = static_cast<s64>(deletions[r].size()) - static_cast<s64>(insertions[r].size());
+            read_chrom_spaces[r] = std::min(read_length + indel_effect, frag_len);
+            if (reads[r].size() != read_chrom_spaces[r]) reads[r].resize(read_chrom_spaces[r], 'N');
+            read_chrom_spaces[r] -= barcode.size();
+        }
+    }
+    // src/hts_illumina.cpp:236-265 (and the body of :192-226 after the chromosome pick)
+    void indels_frag(Pcg64& eng) {
+        u64 chrom_len = genome->chrom_sizes[chrom_ind];
+        frag_len = static_cast<u64>(frag_lengths(eng));
+        if (frag_len < frag_len_min) frag_len = frag_len_min;
+        if (frag_len > frag_len_max) frag_len = frag_len_max;
+        if (frag_len >= chrom_len) {
+            frag_len = chrom_len;
+            frag_start = 0;
+        } else {
+            double u = runif_01(eng);
+            frag_start = static_cast<u64>(u * (chrom_len - frag_len + 1));
+        }
+        sample_indels(eng);
+        adjust_chrom_spaces();
+    }
+    // src/hts_illumina.cpp:192-226
+    void chrom_indels_frag(Pcg64& eng) {
+        chrom_ind = 0;
+        while (chrom_ind < chrom_reads.size() && chrom_reads[chrom_ind] == 0) chrom_ind++;
+        if (chrom_ind == genome->chroms.size()) return;
+        indels_frag(eng);
+    }
+    // src/hts_illumina.cpp:273-282
+    void just_indels(Pcg64& eng) { sample_indels(eng); adjust_chrom_spaces(); }
+
+    // src/hts_illumina.cpp:339-409 (ref_variant = true) and :414-482 (string overload)
+    void append_pools(const std::string& chrom, std::vector<std::vector<char>>& pools, Pcg64& eng,
+                      bool ref_variant) {
+        u64 n_read_ends = ins_probs.size();
+        if (pools.size() != n_read_ends) pools.resize(n_read_ends);
+        bool reverse = runif_01(eng) < 0.5;
+        for (u64 i = 0; i < n_read_ends; i++) {
+            std::string& read = reads[i];
+            std::string& qual = quals[i];
+            u64 start;
+            if ((!matepair && !reverse) || (matepair && reverse)) start = frag_start;
+            else start = frag_start + frag_len - read_chrom_spaces[i];
+            if (!reverse) {
+                fill_read(chrom, read, barcode.size(), start, read_chrom_spaces[i]);
+            } else {
+                fill_read(chrom, read, 0, start, read_chrom_spaces[i]);
+                rev_comp(read);
+            }
+            for (u64 b = 0; b < barcode.size(); b++) read[b] = barcode[b];
+            qual_errors[i].fill_read_qual(read, qual, insertions[i], deletions[i], eng);
+            fill_fq_lines(pools[i], genome->name, genome->chrom_names[chrom_ind], read, qual, i, start,
+                          paired, reverse);
+        }
+        if (ref_variant) {
+            if (chrom_reads[chrom_ind] < n_read_ends) chrom_reads[chrom_ind] = 0;
+            else chrom_reads[chrom_ind] -= n_read_ends;
+        }
+    }
+
+    // src/hts_illumina.cpp:35-53 / :82-93
+    void one_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
+        chrom_indels_frag(eng);
+        if (chrom_ind == genome->chroms.size()) { finished = true; return; }
+        append_pools(*genome->chroms[chrom_ind], pools, eng, true);
+    }
+    void re_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
+        (void)finished;
+        just_indels(eng);
+        append_pools(*genome->chroms[chrom_ind], pools, eng, true);
+    }
+    // string overloads used by the haplotype path: src/hts_illumina.cpp:58-74 / :96-110
+    void one_read_str(const std::string& chrom, u64 chrom_i, std::vector<std::vector<char>>& pools, Pcg64& eng) {
+        chrom_ind = chrom_i;
+        indels_frag(eng);
+        append_pools(chrom, pools, eng, false);
+    }
+    void re_read_str(const std::string& chrom, u64 chrom_i, std::vector<std::vector<char>>& pools, Pcg64& eng) {
+        chrom_ind = chrom_i;
+        just_indels(eng);
+        append_pools(chrom, pools, eng, false);
+    }
+};
+
+// -------------------------------------------------------------------------------------
+// Haplotypes: mutation table read side (src/hap_classes.h:100-258,314-333,439-455;
+// src/hap_classes.cpp:80-116).
+// -------------------------------------------------------------------------------------
+struct HapChrom {
+    const std::string* ref;        // reference chromosome
+    std::vector<u64> old_pos, new_pos;
+    std::vector<std::string> nucleos;   // "" for a deletion (reference: nullptr)
+    u64 chrom_size;
+    std::string name;
+
+    s64 size_modifier(u64 ind) const {
+        s64 size_mod;
+        if (ind < (new_pos.size() - 1)) size_mod = new_pos[ind + 1] - old_pos[ind + 1];
+        else size_mod = chrom_size - ref->size();
+        size_mod += static_cast<s64>(old_pos[ind] - new_pos[ind]);
+        return size_mod;
+    }
+    char get_char_(u64 pos, u64 mut_i) const {
+        u64 ind = pos - new_pos[mut_i];
+        if (static_cast<s64>(ind) > size_modifier(mut_i)) {
+            ind += (old_pos[mut_i] - size_modifier(mut_i));
+            return (*ref)[ind];
+        }
+        if (nucleos[mut_i].empty()) throw std::runtime_error("mutations.nucleos[mut_i] == nullptr");
+        return nucleos[mut_i][ind];
+    }
+    std::string get_chrom_full() const {
+        if (new_pos.empty()) return *ref;
+        u64 mut_i = 0, pos = 0;
+        std::string out; out.reserve(chrom_size);
+        while (pos < new_pos[mut_i]) { out.push_back((*ref)[pos]); ++pos; }
+        u64 next_mut_i = mut_i + 1;
+        while (next_mut_i < new_pos.size()) {
+            while (pos < new_pos[next_mut_i]) { out.push_back(get_char_(pos, mut_i)); ++pos; }
+            ++mut_i; ++next_mut_i;
+        }
+        while (pos < chrom_size) { out.push_back(get_char_(pos, mut_i)); ++pos; }
+        return out;
+    }
+};
+
+struct HapGenome { std::string name; std::vector<HapChrom> chroms; };
+
+// IlluminaHaplotypes (src/hts_illumina.h:509-675, src/hts_illumina.cpp:495-558)
+struct IlluminaHaplotypes {
+    const std::vector<HapGenome>* haps;
+    std::vector<Genome> genomes;                 // name/chrom-name/size views per haplotype
+    std::vector<std::vector<u64>> n_reads_vc;
+    std::vector<IlluminaOneGenome> read_makers;
+    bool paired;
+    std::vector<double> hap_probs;
+    u64 hap, chr;
+    std::string hap_chrom_seq;
+
+    IlluminaHaplotypes(const std::vector<HapGenome>& hs, const std::vector<double>& probs,
+                       const IlluminaParams& p, std::vector<std::string> barcodes)
+        : haps(&hs), paired(p.paired), hap_probs(probs), hap(0), chr(0) {
+        if (barcodes.size() < hs.size()) barcodes.resize(hs.size(), "");
+        genomes.resize(hs.size());
+        for (u64 i = 0; i < hs.size(); i++) {
+            genomes[i].name = hs[i].name;
+            for (const HapChrom& hc : hs[i].chroms) {
+                genomes[i].chrom_names.push_back(hc.name);
+                genomes[i].chroms.push_back(nullptr);
+                genomes[i].chrom_sizes.push_back(hc.chrom_size);
+            }
+        }
+        read_makers.reserve(hs.size());
+        for (u64 i = 0; i < hs.size(); i++) read_makers.push_back(IlluminaOneGenome(genomes[i], p, barcodes[i]));
+    }
+    // The copy made per thread must re-point each read maker at this object's genome views.
+    IlluminaHaplotypes(const IlluminaHaplotypes& o)
+        : haps(o.haps), genomes(o.genomes), n_reads_vc(o.n_reads_vc), read_makers(o.read_makers),
+          paired(o.paired), hap_probs(o.hap_probs), hap(o.hap), chr(o.chr), hap_chrom_seq(o.hap_chrom_seq) {
+        for (u64 i = 0; i < read_makers.size(); i++) read_makers[i].genome = &genomes[i];
+    }
+
+    // src/hts_illumina.h:620-644
+    void add_n_reads(u64 n_reads, SeedSource& seeds) {
+        u64 n_haps = haps->size();
+        if (paired) n_reads /= 2;
+        std::vector<u64> hap_reads = reads_per_group(n_reads, hap_probs, seeds);
+        for (u64 v = 0; v < n_haps; v++) {
+            std::vector<double> chrom_probs;
+            for (const HapChrom& vc : (*haps)[v].chroms) chrom_probs.push_back(vc.chrom_size);
+            n_reads_vc.push_back(reads_per_group(hap_reads[v], chrom_probs, seeds));
+            if (paired) for (u64& r : n_reads_vc.back()) r *= 2;
+        }
+        for (u64 i = 0; i < n_haps; i++) read_makers[i].add_n_reads(hap_reads[i], seeds);
+    }
+    // src/hts_illumina.cpp:495-536
+    void one_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
+        if (hap == haps->size()) { finished = true; return; }
+        if (n_reads_vc[hap][chr] == 0 || hap_chrom_seq.empty()) {
+            u64 new_hap = hap, new_chr = chr;
+            for (; new_hap < n_reads_vc.size(); new_hap++) {
+                while (n_reads_vc[new_hap][new_chr] == 0) {
+                    new_chr++;
+                    if (new_chr == n_reads_vc[new_hap].size()) break;
+                }
+                if (new_chr < n_reads_vc[new_hap].size()) break;
+                else new_chr = 0;
+            }
+            hap = new_hap; chr = new_chr;
+            if (hap == haps->size()) { finished = true; return; }
+            hap_chrom_seq = (*haps)[hap].chroms[chr].get_chrom_full();
+        }
+        read_makers[hap].one_read_str(hap_chrom_seq, chr, pools, eng);
+        n_reads_vc[hap][chr]--;
+        if (paired && n_reads_vc[hap][chr] > 0) n_reads_vc[hap][chr]--;
+    }
+    // src/hts_illumina.cpp:542-558
+    void re_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
+        if (hap == haps->size()) { finished = true; return; }
+        read_makers[hap].re_read_str(hap_chrom_seq, chr, pools, eng);
+        if (n_reads_vc[hap][chr] > 0) n_reads_vc[hap][chr]--;
+        if (paired && n_reads_vc[hap][chr] > 0) n_reads_vc[hap][chr]--;
+    }
+};
+
+// -------------------------------------------------------------------------------------
+// Driver: ReadWriterOneThread::create_reads + write_reads_one_filetype_ (src/hts.h:193-429)
+// restated for T sequential "threads".  Output = thread 0's pools, then thread 1's, ...
+// (one of the interleavings the reference's `omp critical` flush can produce).
+// -------------------------------------------------------------------------------------
+template <typename Filler>
+static void run_threads(const Filler& base, u64 n_reads, double prob_dup, u64 read_pool_size, u64 n_read_ends,
+                        u64 n_threads, SeedSource& seeds, std::vector<std::vector<char>>& files) {
+    n_reads /= n_read_ends;
+    std::vector<u64> reads_per_thread = split_int(n_reads, n_threads);
+    for (u64& i : reads_per_thread) i *= n_read_ends;
+    // mt_seeds first (src/hts.h:339), then one filler copy + add_n_reads per thread (:349-353)
+    std::vector<const uint32_t*> tseeds(n_threads);
+    for (u64 t = 0; t < n_threads; t++) tseeds[t] = seeds.take8();
+    std::vector<Filler> fillers;
+    fillers.reserve(n_threads);
+    for (u64 t = 0; t < n_threads; t++) {
+        fillers.push_back(base);
+        fillers.back().add_n_reads(reads_per_thread[t], seeds);
+    }
+    files.assign(n_read_ends, std::vector<char>());
+    for (u64 t = 0; t < n_threads; t++) {
+        Pcg64 eng = seeded_pcg(tseeds[t]);
+        Filler& filler = fillers[t];
+        const u64 n = reads_per_thread[t];
+        u64 reads_made = 0, reads_in_pool = 0;
+        std::vector<std::vector<char>> pools(n_read_ends);
+        while (reads_made < n) {
+            bool do_write;
+            bool finished = false;
+            filler.one_read(pools, finished, eng);
+            if (finished) { reads_made = n; do_write = true; }
+            else {
+                reads_made += n_read_ends; reads_in_pool += n_read_ends;
+                double dup = runif_01(eng);
+                bool fin2 = false;
+                while (dup < prob_dup && reads_made < n && reads_in_pool < read_pool_size) {
+                    filler.re_read(pools, finished, eng);
+                    if (finished) { reads_made = n; fin2 = true; break; }
+                    reads_made += n_read_ends; reads_in_pool += n_read_ends;
+                    dup = runif_01(eng);
+                }
+                do_write = fin2 || reads_in_pool >= read_pool_size || reads_made >= n;
+            }
+            if (do_write) {
+                for (u64 i = 0; i < pools.size(); i++) {
+                    files[i].insert(files[i].end(), pools[i].begin(), pools[i].end());
+                    pools[i].clear();
+                }
+                reads_in_pool = 0;
+            }
+        }
+    }
+}
+
+// helpers to unflatten C inputs
+static Profile make_profile(uint32_t L, const uint32_t* n_quals, const double* probs, const uint8_t* quals) {
+    Profile p; p.probs.resize(4); p.quals.resize(4);
+    u64 off = 0;
+    for (int nt = 0; nt < 4; nt++) {
+        p.probs[nt].resize(L); p.quals[nt].resize(L);
+        for (uint32_t pos = 0; pos < L; pos++) {
+            uint32_t k = n_quals[nt * L + pos];
+            p.probs[nt][pos].assign(probs + off, probs + off + k);
+            p.quals[nt][pos].assign(quals + off, quals + off + k);
+            off += k;
+        }
+    }
+    return p;
+}
+
+static void give(const std::vector<char>& v, char** out, uint64_t* len) {
+    *len = v.size();
+    *out = static_cast<char*>(std::malloc(v.size() ? v.size() : 1));
+    if (!v.empty()) std::memcpy(*out, v.data(), v.size());
+}
+
+static thread_local std::string g_err;
+
+}  // namespace orc
+
+using namespace orc;
+
+extern "C" {
+
+const char* orc_last_error(void) { return g_err.c_str(); }
+void orc_free(void* p) { std::free(p); }
+
+void orc_pcg64_outputs(const uint32_t* sub_seeds, uint64_t n, uint64_t* out) {
+    Pcg64 e = seeded_pcg(sub_seeds);
+    for (uint64_t i = 0; i < n; i++) out[i] = e();
+}
+
+// Elementary conversions, evaluated with the reference's x87 expressions.
+uint64_t orc_index(uint64_t x, uint64_t n) { return static_cast<uint64_t>(runif_01_from(x) * n); }         // alias_sampler.h:55
+uint64_t orc_index_d(uint64_t x, double n) { return static_cast<uint64_t>(runif_01_from(x) * n); }          // hts_illumina.h:216,254
+double orc_u01_double(uint64_t x) { double u = runif_01_from(x); return u; }                                   // alias_sampler.h:57
+uint8_t orc_nqual(uint64_t x) { u8 q = runif_01_from(x) * 10 + static_cast<u8>('!'); return q; }              // hts_illumina.h:238
+int orc_lt_half(uint64_t x) { return runif_01_from(x) < 0.5; }                                                 // hts_illumina.cpp:352
+double orc_canonical(uint64_t x) {   // libstdc++ generate_canonical<double,53> over a 64-bit URBG (random.tcc:3348-3380)
+    struct One { typedef uint64_t result_type; uint64_t v; static constexpr uint64_t min() { return 0; }
+                 static constexpr uint64_t max() { return ~uint64_t(0); } uint64_t operator()() { return v; } } g{x};
+    return std::generate_canonical<double, 53>(g);
+}
+uint64_t orc_frag_start(uint64_t x, uint64_t span) { double u = runif_01_from(x); return static_cast<uint64_t>(u * span); }  // hts_illumina.cpp:215-216
+double orc_log(double x) { return std::log(x); }
+double orc_qual_prob(uint32_t q) { return q == 0 ? 1.0 : std::pow(10, static_cast<double>(q) / -10.0); }
+
+// Vectorised form of the primitives above with the operation codes of include/jackalope_hip.h
+// (JK_OP_*), so tests can compare millions of inputs without per-call ctypes overhead.
+void orc_eval_many(int what, const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out) {
+    auto bits = [](double d) { uint64_t u; std::memcpy(&u, &d, 8); return u; };
+    auto dbl = [](uint64_t u) { double d; std::memcpy(&d, &u, 8); return d; };
+    for (uint64_t i = 0; i < n; i++) {
+        switch (what) {
+            case 0: { uint32_t w[8]; for (int k = 0; k < 8; k++) w[k] = (uint32_t)in[i * 8 + k];
+                      Pcg64 e = seeded_pcg(w); for (uint64_t k = 0; k < aux; k++) out[i * aux + k] = e(); break; }
+            case 1: out[i] = orc_index(in[i], aux); break;
+            case 2: out[i] = bits(orc_u01_double(in[i])); break;
+            case 3: out[i] = bits(orc_canonical(in[i])); break;
+            case 4: out[i] = orc_nqual(in[i]); break;
+            case 5: out[i] = orc_lt_half(in[i]); break;
+            case 6: out[i] = orc_frag_start(in[i], aux); break;
+            case 7: out[i] = bits(std::log(dbl(in[i]))); break;
+            case 8: out[i] = bits(std::sqrt(dbl(in[i]))); break;
+            default: break;
+        }
+    }
+}
+static double g_gamma_shape = 16.0, g_gamma_scale = 25.0;
+void orc_set_gamma(double shape, double scale) { g_gamma_shape = shape; g_gamma_scale = scale; }
+// JK_OP_GAMMA_STREAM: `aux` std::gamma_distribution draws per seeded engine (hts_illumina.cpp:206)
+void orc_gamma_streams(const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out) {
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t w[8]; for (int k = 0; k < 8; k++) w[k] = (uint32_t)in[i * 8 + k];
+        Pcg64 e = seeded_pcg(w);
+        std::gamma_distribution<double> g(g_gamma_shape, g_gamma_scale);
+        for (uint64_t k = 0; k < aux; k++) { double d = g(e); std::memcpy(&out[i * aux + k], &d, 8); }
+    }
+}
+
+void orc_alias_build(const double* probs, uint64_t n, double* Prob, uint64_t* Ali) {
+    Alias a(std::vector<double>(probs, probs + n));
+    for (uint64_t i = 0; i < n; i++) { Prob[i] = a.Prob[i]; Ali[i] = a.Ali[i]; }
+}
+
+// n gamma fragment lengths + the engine outputs consumed, for one seeded engine (hts_illumina.cpp:206)
+void orc_gamma_draws(const uint32_t* sub_seeds, double shape, double scale, uint64_t n, double* out) {
+    Pcg64 e = seeded_pcg(sub_seeds);
+    std::gamma_distribution<double> g(shape, scale);
+    for (uint64_t i = 0; i < n; i++) out[i] = g(e);
+}
+
+void orc_split_int(uint64_t x, uint64_t n, uint64_t* out) {
+    std::vector<u64> v = split_int(x, n);
+    for (uint64_t i = 0; i < n; i++) out[i] = v[i];
+}
+int orc_reads_per_group(uint64_t n_reads, const double* probs, uint64_t n, const uint32_t* seed_words,
+                        uint64_t n_seed_words, uint64_t* out, uint64_t* words_used) {
+    try {
+        SeedSource s{seed_words, n_seed_words, 0};
+        std::vector<u64> v = reads_per_group(n_reads, std::vector<double>(probs, probs + n), s);
+        for (uint64_t i = 0; i < n; i++) out[i] = v[i];
+        *words_used = s.pos;
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+void orc_rev_comp(char* s, uint64_t n) { std::string t(s, n); rev_comp(t); std::memcpy(s, t.data(), n); }
+
+struct orc_illumina_args {
+    int32_t paired, matepair;
+    uint64_t n_reads;
+    double prob_dup;
+    uint64_t n_threads, read_pool_size;
+    double frag_len_shape, frag_len_scale;
+    uint64_t frag_len_min, frag_len_max;
+    uint32_t read_length;
+    const uint32_t* n_quals1; const double* probs1; const uint8_t* quals1; double ins_prob1, del_prob1;
+    const uint32_t* n_quals2; const double* probs2; const uint8_t* quals2; double ins_prob2, del_prob2;
+    const uint32_t* seed_words; uint64_t n_seed_words;
+};
+
+static IlluminaParams to_params(const orc_illumina_args* a) {
+    IlluminaParams p;
+    p.paired = a->paired; p.matepair = a->matepair;
+    p.shape = a->frag_len_shape; p.scale = a->frag_len_scale;
+    p.frag_len_min = a->frag_len_min; p.frag_len_max = a->frag_len_max;
+    p.prof[0] = make_profile(a->read_length, a->n_quals1, a->probs1, a->quals1);
+    p.ins_prob[0] = a->ins_prob1; p.del_prob[0] = a->del_prob1;
+    if (a->paired) {
+        p.prof[1] = make_profile(a->read_length, a->n_quals2, a->probs2, a->quals2);
+        p.ins_prob[1] = a->ins_prob2; p.del_prob[1] = a->del_prob2;
+    }
+    return p;
+}
+
+// illumina_ref_cpp (src/hts_illumina.cpp:589-649) with uncompressed sinks returned in memory.
+// Filler wrapper so run_threads' add_n_reads(n, seeds) signature is shared.
+int orc_illumina_ref(uint64_t n_chroms, const char* const* chrom_names, const char* const* chrom_seqs,
+                     const uint64_t* chrom_lens, const orc_illumina_args* a, const char* barcode,
+                     char** out1, uint64_t* len1, char** out2, uint64_t* len2, uint64_t* seed_words_used) {
+    try {
+        std::vector<std::string> seqs(n_chroms);
+        Genome g; g.name = "REF";
+        for (uint64_t i = 0; i < n_chroms; i++) {
+            seqs[i].assign(chrom_seqs[i], chrom_lens[i]);
+            g.chrom_names.push_back(chrom_names[i]);
+            g.chrom_sizes.push_back(chrom_lens[i]);
+        }
+        for (uint64_t i = 0; i < n_chroms; i++) g.chroms.push_back(&seqs[i]);
+        IlluminaParams p = to_params(a);
+        IlluminaOneGenome base(g, p, barcode ? barcode : "");
+        SeedSource seeds{a->seed_words, a->n_seed_words, 0};
+        std::vector<std::vector<char>> files;
+        run_threads(base, a->n_reads, a->prob_dup, a->read_pool_size, a->paired ? 2 : 1, a->n_threads, seeds, files);
+        give(files[0], out1, len1);
+        if (a->paired) give(files[1], out2, len2); else { *out2 = nullptr; *len2 = 0; }
+        if (seed_words_used) *seed_words_used = seeds.pos;
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// Haplotype set handed over as flat arrays: for haplotype h, chromosome c (index h*n_chroms+c):
+// chrom_size, n_mut, then mutation arrays concatenated in (h,c) order; nucleos as one blob with
+// per-mutation offsets (n_mut_total+1 entries; equal consecutive offsets = deletion).
+struct orc_hap_set {
+    uint64_t n_haps, n_chroms;
+    const char* const* hap_names;
+    const char* const* chrom_names; const char* const* ref_seqs; const uint64_t* ref_lens;
+    const uint64_t* chrom_size; const uint64_t* n_mut;
+    const uint64_t* old_pos; const uint64_t* new_pos; const uint64_t* nuc_off; const char* nuc_blob;
+};
+
+static void build_haps(const orc_hap_set* hs, std::vector<std::string>& refs, std::vector<HapGenome>& haps) {
+    refs.resize(hs->n_chroms);
+    for (uint64_t c = 0; c < hs->n_chroms; c++) refs[c].assign(hs->ref_seqs[c], hs->ref_lens[c]);
+    haps.resize(hs->n_haps);
+    uint64_t m = 0;
+    for (uint64_t h = 0; h < hs->n_haps; h++) {
+        haps[h].name = hs->hap_names[h];
+        haps[h].chroms.resize(hs->n_chroms);
+        for (uint64_t c = 0; c < hs->n_chroms; c++) {
+            HapChrom& hc = haps[h].chroms[c];
+            uint64_t idx = h * hs->n_chroms + c;
+            hc.ref = &refs[c]; hc.name = hs->chrom_names[c]; hc.chrom_size = hs->chrom_size[idx];
+            for (uint64_t j = 0; j < hs->n_mut[idx]; j++, m++) {
+                hc.old_pos.push_back(hs->old_pos[m]); hc.new_pos.push_back(hs->new_pos[m]);
+                hc.nucleos.push_back(std::string(hs->nuc_blob + hs->nuc_off[m], hs->nuc_off[m + 1] - hs->nuc_off[m]));
+            }
+        }
+    }
+}
+
+// HapChrom::get_chrom_full for (hap, chrom) -- src/hap_classes.cpp:80-116
+int orc_hap_chrom_full(const orc_hap_set* hs, uint64_t hap, uint64_t chrom, char** out, uint64_t* len) {
+    try {
+        std::vector<std::string> refs; std::vector<HapGenome> haps;
+        build_haps(hs, refs, haps);
+        std::string s = haps[hap].chroms[chrom].get_chrom_full();
+        *len = s.size(); *out = static_cast<char*>(std::malloc(s.size() ? s.size() : 1));
+        std::memcpy(*out, s.data(), s.size());
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// illumina_hap_cpp (src/hts_illumina.cpp:662-739), sep_files = FALSE, uncompressed.
+int orc_illumina_hap(const orc_hap_set* hs, const double* hap_probs, const orc_illumina_args* a,
+                     const char* const* barcodes, uint64_t n_barcodes,
+                     char** out1, uint64_t* len1, char** out2, uint64_t* len2, uint64_t* seed_words_used) {
+    try {
+        std::vector<std::string> refs; std::vector<HapGenome> haps;
+        build_haps(hs, refs, haps);
+        IlluminaParams p = to_params(a);
+        std::vector<std::string> bcs;
+        for (uint64_t i = 0; i < n_barcodes; i++) bcs.push_back(barcodes[i]);
+        IlluminaHaplotypes base(haps, std::vector<double>(hap_probs, hap_probs + hs->n_haps), p, bcs);
+        SeedSource seeds{a->seed_words, a->n_seed_words, 0};
+        std::vector<std::vector<char>> files;
+        run_threads(base, a->n_reads, a->prob_dup, a->read_pool_size, a->paired ? 2 : 1, a->n_threads, seeds, files);
+        give(files[0], out1, len1);
+        if (a->paired) give(files[1], out2, len2); else { *out2 = nullptr; *len2 = 0; }
+        if (seed_words_used) *seed_words_used = seeds.pos;
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+}  // extern "C"

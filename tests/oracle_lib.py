@@ -1,0 +1,148 @@
+"""ctypes access to the CPU oracle (oracle/libjk_oracle.so) -- test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "libjk_oracle.so")
+REF_PCG_SO = os.path.join(ORACLE_DIR, "_ref", "libref_pcg.so")
+
+
+class OrcIlluminaArgs(C.Structure):
+    _fields_ = [("paired", C.c_int32), ("matepair", C.c_int32), ("n_reads", C.c_uint64), ("prob_dup", C.c_double),
+                ("n_threads", C.c_uint64), ("read_pool_size", C.c_uint64),
+                ("frag_len_shape", C.c_double), ("frag_len_scale", C.c_double),
+                ("frag_len_min", C.c_uint64), ("frag_len_max", C.c_uint64), ("read_length", C.c_uint32),
+                ("n_quals1", C.c_void_p), ("probs1", C.c_void_p), ("quals1", C.c_void_p),
+                ("ins_prob1", C.c_double), ("del_prob1", C.c_double),
+                ("n_quals2", C.c_void_p), ("probs2", C.c_void_p), ("quals2", C.c_void_p),
+                ("ins_prob2", C.c_double), ("del_prob2", C.c_double),
+                ("seed_words", C.c_void_p), ("n_seed_words", C.c_uint64)]
+
+
+class OrcHapSet(C.Structure):
+    _fields_ = [("n_haps", C.c_uint64), ("n_chroms", C.c_uint64),
+                ("hap_names", C.POINTER(C.c_char_p)), ("chrom_names", C.POINTER(C.c_char_p)),
+                ("ref_seqs", C.POINTER(C.c_void_p)), ("ref_lens", C.POINTER(C.c_uint64)),
+                ("chrom_size", C.c_void_p), ("n_mut", C.c_void_p), ("old_pos", C.c_void_p),
+                ("new_pos", C.c_void_p), ("nuc_off", C.c_void_p), ("nuc_blob", C.c_void_p)]
+
+
+_lib = None
+
+
+def build():
+    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(ORACLE_DIR, "jk_oracle.cpp")):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(ORACLE_SO)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_index.restype = C.c_uint64
+        L.orc_index.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_index_d.restype = C.c_uint64
+        L.orc_index_d.argtypes = [C.c_uint64, C.c_double]
+        L.orc_u01_double.restype = C.c_double
+        L.orc_u01_double.argtypes = [C.c_uint64]
+        L.orc_nqual.restype = C.c_uint8
+        L.orc_nqual.argtypes = [C.c_uint64]
+        L.orc_lt_half.restype = C.c_int
+        L.orc_lt_half.argtypes = [C.c_uint64]
+        L.orc_canonical.restype = C.c_double
+        L.orc_canonical.argtypes = [C.c_uint64]
+        L.orc_frag_start.restype = C.c_uint64
+        L.orc_frag_start.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_log.restype = C.c_double
+        L.orc_log.argtypes = [C.c_double]
+        L.orc_qual_prob.restype = C.c_double
+        L.orc_qual_prob.argtypes = [C.c_uint32]
+        L.orc_eval_many.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def ref_pcg_lib():
+    """The reference's own PCG headers compiled by oracle/Makefile (None when not built)."""
+    if not os.path.exists(REF_PCG_SO):
+        return None
+    return C.CDLL(REF_PCG_SO)
+
+
+def pcg64_outputs(words8, n, use_ref=False):
+    words8 = np.ascontiguousarray(words8, dtype=np.uint32)
+    out = np.zeros(n, dtype=np.uint64)
+    if use_ref:
+        ref_pcg_lib().ref_pcg64_outputs(words8.ctypes.data_as(C.c_void_p), C.c_uint64(n), out.ctypes.data_as(C.c_void_p))
+    else:
+        lib().orc_pcg64_outputs(words8.ctypes.data_as(C.c_void_p), C.c_uint64(n), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def eval_many(what, xs, aux=0):
+    """Vectorised primitive evaluation with the oracle's x87 expressions (same `what` codes as the ABI)."""
+    xs = np.ascontiguousarray(xs, dtype=np.uint64)
+    stream = what in (0, 9)
+    n = xs.size // 8 if stream else xs.size
+    out = np.zeros(n * aux if stream else n, dtype=np.uint64)
+    lib().orc_eval_many(what, xs.ctypes.data, n, aux, out.ctypes.data)
+    return out
+
+
+def alias_build(probs):
+    probs = np.ascontiguousarray(probs, dtype=np.float64)
+    P = np.zeros(probs.size, dtype=np.float64)
+    A = np.zeros(probs.size, dtype=np.uint64)
+    lib().orc_alias_build(probs.ctypes.data_as(C.c_void_p), C.c_uint64(probs.size), P.ctypes.data_as(C.c_void_p),
+                          A.ctypes.data_as(C.c_void_p))
+    return P, A
+
+
+def _take(ptr, n):
+    data = C.string_at(ptr, n) if n else b""
+    lib().orc_free(ptr)
+    return data
+
+
+def _args(paired, matepair, n_reads, prob_dup, n_threads, read_pool_size, shape, scale, fmin, fmax, prof1, prof2,
+          ins1, del1, ins2, del2, words):
+    a = OrcIlluminaArgs()
+    a.paired, a.matepair = int(paired), int(matepair)
+    a.n_reads, a.prob_dup, a.n_threads, a.read_pool_size = int(n_reads), float(prob_dup), int(n_threads), int(read_pool_size)
+    a.frag_len_shape, a.frag_len_scale, a.frag_len_min, a.frag_len_max = float(shape), float(scale), int(fmin), int(fmax)
+    a.read_length = prof1.read_length
+    a.n_quals1, a.probs1, a.quals1 = prof1.n_quals.ctypes.data, prof1.probs.ctypes.data, prof1.quals.ctypes.data
+    a.ins_prob1, a.del_prob1 = float(ins1), float(del1)
+    if paired:
+        a.n_quals2, a.probs2, a.quals2 = prof2.n_quals.ctypes.data, prof2.probs.ctypes.data, prof2.quals.ctypes.data
+    a.ins_prob2, a.del_prob2 = float(ins2), float(del2)
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    a.seed_words, a.n_seed_words = words.ctypes.data, words.size
+    return a, words
+
+
+def illumina_ref(genome, *, paired, matepair=False, n_reads, prob_dup, n_threads, read_pool_size, shape, scale, fmin,
+                 fmax, prof1, prof2=None, ins1, del1, ins2=0.0, del2=0.0, barcode="", words):
+    """Oracle run of illumina_ref_cpp; returns (fastq_R1 bytes, fastq_R2 bytes or None, seed words used)."""
+    a, keep = _args(paired, matepair, n_reads, prob_dup, n_threads, read_pool_size, shape, scale, fmin, fmax, prof1,
+                    prof2, ins1, del1, ins2, del2, words)
+    n = genome.n_chroms()
+    names = (C.c_char_p * n)(*[x.encode() for x in genome.names])
+    seqs = (C.c_void_p * n)(*[s.ctypes.data for s in genome.seqs])
+    lens = (C.c_uint64 * n)(*genome.sizes())
+    o1, o2 = C.c_void_p(), C.c_void_p()
+    l1, l2, used = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = lib().orc_illumina_ref(C.c_uint64(n), names, seqs, lens, C.byref(a), barcode.encode(), C.byref(o1), C.byref(l1),
+                                C.byref(o2), C.byref(l2), C.byref(used))
+    if rc != 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+    r1 = _take(o1, l1.value)
+    r2 = _take(o2, l2.value) if paired else None
+    return r1, r2, used.value
