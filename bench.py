@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the read-generation hot path on MI355X.
+
+Metric (BASELINE.json): M paired reads/sec for Illumina PE150 at 30x of a 100 Mbp synthetic
+reference (configs[1]), per GPU count, plus the achieved fraction of the HBM roofline and the CPU
+path (the oracle restatement of the reference) timed on this box's host cores in the same run.
+
+A "step" is one pass of the hot path over the whole 30x job of one GPU: 10 M read pairs generated
+by `--lanes` independent generator streams, pool-compacted into the two lane-major FASTQ images,
+all resident in HBM (genome, tables, seeds and quotas are uploaded before the timed region; nothing
+is copied to the host inside it).  With N GPUs the job is N x 10 M pairs over N x lanes lanes and
+rank r generates lane block r (weak scaling; no data-path collective -- the only exchange is the
+all-gather of per-rank pair/byte counts after the timed region).
+
+  python bench.py [--gpus N --steps K --warmup W] [--lanes L] [--pairs P] [--genome-mbp G]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(genome, prof1, prof2, read_length, sample_pairs, cores):
+    """Time the CPU oracle (port of the reference's path) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    import jackalope_amd as ja
+    O.lib().orc_set_threads(cores)
+    lanes = max(cores * 8, 8)
+    words = ja.seed_words(12345, 16 * lanes)
+    t0 = time.perf_counter()
+    r1, r2, _ = O.illumina_ref(genome, paired=True, n_reads=2 * sample_pairs, prob_dup=0.02, n_threads=lanes,
+                               read_pool_size=1000, shape=16.0, scale=25.0, fmin=read_length, fmax=2 ** 32 - 1,
+                               prof1=prof1, prof2=prof2, ins1=0.00009, del1=0.00011, ins2=0.00015, del2=0.00023,
+                               words=words)
+    dt = time.perf_counter() - t0
+    pairs = r1.count(b"\n") // 4
+    return {"value": round(pairs / dt / 1e6, 6), "unit": "M paired reads/sec", "cores": cores, "kind": "port",
+            "sample": "%d pairs of the same 100 Mbp PE150 workload on %d lanes, oracle/jk_oracle.cpp with OpenMP, "
+                      "FASTQ kept in memory (%.1f s)" % (pairs, lanes, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--lanes", type=int, default=1 << 20, help="generator lanes per GPU")
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU (30x of 100 Mbp at PE150)")
+    ap.add_argument("--genome-mbp", type=float, default=100.0)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = choose for about 15 s of CPU work")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % a.gpus)
+        a.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import jackalope_amd as ja
+
+    read_length = 150
+    genome = ja.synthetic_genome([int(a.genome_mbp * 1e6)], seed=2)
+    total_lanes = a.lanes * world
+    n_reads = 2 * a.pairs * world
+    words = ja.seed_words(12345, 16 * total_lanes)
+    sess = ja.illumina(genome, None, n_reads, read_length, True, n_threads=total_lanes, seed_words=words,
+                       device=local_rank, lane_begin=rank * a.lanes, lane_end=(rank + 1) * a.lanes, _session=True)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        sess.generate()
+    sync()
+    t0 = time.perf_counter()
+    gen_ms = 0.0
+    all_ms = 0.0
+    for _ in range(a.steps):
+        sess.generate()                      # blocks until the step's stream work is done
+        tm = sess.timing_ms()                # HIP events on the stream the kernels run on
+        gen_ms += tm["generate_kernel"]
+        all_ms += tm["total"]
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    sizes, reads_made = sess.sizes()
+    pairs_rank = reads_made // 2
+    fastq_bytes = sum(sizes)
+
+    # count exchange over RCCL: per-rank {pairs, bytes R1, bytes R2}; max over ranks of the time
+    stats = torch.tensor([pairs_rank, sizes[0], sizes[1]], dtype=torch.int64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        total_pairs = int(sum(int(g[0]) for g in gathered))
+    else:
+        total_pairs = pairs_rank
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        value = total_pairs * a.steps / elapsed / 1e6
+        # roofline of the dominant kernel (the generator): algorithmic bytes per launch = FASTQ bytes it
+        # emits + 300 reference bytes per pair, over its average HIP-event duration
+        alg_bytes = fastq_bytes + 300 * pairs_rank
+        kern_s = gen_ms / a.steps / 1e3
+        achieved = alg_bytes / kern_s / 1e9
+        out = {
+            "metric": "M paired reads/sec (PE150, 30x of 100 Mbp)", "value": round(value, 3),
+            "unit": "M paired reads/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[1]: %g Mbp synthetic ref (iid TCAG, seed 2), 1 haplotype, 30x Illumina "
+                                   "PE150, HiSeq 2500 profile, default indel/dup probabilities" % a.genome_mbp,
+                       "pairs_per_gpu": a.pairs, "lanes_per_gpu": a.lanes, "read_length": read_length,
+                       "parallelism": "lanes sharded over %d GPU(s), no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel": "illumina_ref_kernel", "kernel_ms": round(gen_ms / a.steps, 3),
+                         "algorithmic_bytes_per_pair": round(alg_bytes / max(pairs_rank, 1), 2),
+                         "note": "integer-ALU bound: ~1200 pcg64 steps (128-bit multiply) per pair; "
+                                 "draws/s = %.3g" % (1206.0 * pairs_rank / kern_s)},
+            "device_ms_per_step": round(all_ms / a.steps, 3),
+        }
+        if not a.no_cpu_baseline:
+            cores = min(os.cpu_count() or 1, 64)
+            sample = a.cpu_sample_pairs or 50_000 * min(cores, 16)
+            p1, p2 = ja.read_profile(None, None, read_length, 1), ja.read_profile(None, None, read_length, 2)
+            out["cpu_baseline"] = cpu_baseline(genome, p1, p2, read_length, sample, cores)
+        print(json.dumps(out))
+    sess.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,16 +11,22 @@ import numpy as np
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "art_profiles")
 
-# name, read_length, read, file stem, abbreviation  (R/hts_illumina.R:17-47); only some are bundled
+# name, read_length, read, file stem, abbreviation  (R/hts_illumina.R:17-47), ordered by read length
 _BUILTIN = [
     ("Genome Analyzer I", 36, 1, "EmpR36R1", "GA1"), ("Genome Analyzer I", 36, 2, "EmpR36R2", "GA1"),
     ("Genome Analyzer I", 44, 1, "EmpR44R1", "GA1"), ("Genome Analyzer I", 44, 2, "EmpR44R2", "GA1"),
     ("Genome Analyzer II", 50, 1, "EmpR50R1", "GA2"), ("Genome Analyzer II", 50, 2, "EmpR50R2", "GA2"),
+    ("MiniSeq TruSeq", 50, 1, "MiniSeqTruSeqL50", "MinS"),
     ("Genome Analyzer II", 75, 1, "EmpR75R1", "GA2"), ("Genome Analyzer II", 75, 2, "EmpR75R2", "GA2"),
+    ("NextSeq 500 v2", 75, 1, "NextSeq500v2L75R1", "NS50"), ("NextSeq 500 v2", 75, 2, "NextSeq500v2L75R2", "NS50"),
+    ("HiSeq 1000", 100, 1, "Emp100R1", "HS10"), ("HiSeq 1000", 100, 2, "Emp100R2", "HS10"),
     ("HiSeq 2000", 100, 1, "HiSeq2000L100R1", "HS20"), ("HiSeq 2000", 100, 2, "HiSeq2000L100R2", "HS20"),
     ("HiSeq 2500", 125, 1, "HiSeq2500L125R1", "HS25"), ("HiSeq 2500", 125, 2, "HiSeq2500L125R2", "HS25"),
     ("HiSeq 2500", 150, 1, "HiSeq2500L150R1filter", "HS25"), ("HiSeq 2500", 150, 2, "HiSeq2500L150R2filter", "HS25"),
+    ("HiSeqX v2.5 PCR free", 150, 1, "HiSeqXPCRfreeL150R1", "HSXn"), ("HiSeqX v2.5 PCR free", 150, 2, "HiSeqXPCRfreeL150R2", "HSXn"),
+    ("HiSeqX v2.5 TruSeq", 150, 1, "HiSeqXtruSeqL150R1", "HSXt"), ("HiSeqX v2.5 TruSeq", 150, 2, "HiSeqXtruSeqL150R2", "HSXt"),
     ("MiSeq v1", 250, 1, "EmpMiSeq250R1", "MSv1"), ("MiSeq v1", 250, 2, "EmpMiSeq250R2", "MSv1"),
+    ("MiSeq v3", 250, 1, "MiSeqv3L250R1", "MSv3"), ("MiSeq v3", 250, 2, "MiSeqv3L250R2", "MSv3"),
 ]
 
 

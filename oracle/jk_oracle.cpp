@@ -34,6 +34,8 @@
 #include <stdexcept>
 #include <algorithm>
 #include <numeric>
+#include <memory>
+#include <omp.h>
 
 namespace orc {
 
@@ -335,7 +337,9 @@ struct IlluminaParams {
 };
 
 struct IlluminaOneGenome {
-    std::vector<QualErr> qual_errors;
+    // The reference copies these tables into every per-thread filler; they are never modified after
+    // construction, so the copies share one instance here (1 M lanes x 300 KB would not fit in RAM).
+    std::vector<std::shared_ptr<const QualErr>> qual_errors;
     std::gamma_distribution<double> frag_lengths;
     std::vector<u64> chrom_reads;
     const Genome* genome;
@@ -359,7 +363,7 @@ struct IlluminaOneGenome {
         if (paired && p.prof[0].probs[0].size() != p.prof[1].probs[0].size())
             throw std::runtime_error("In IlluminaOneGenome constr., read lengths for R1 and R2 don't match.");
         for (u64 r = 0; r < ne; r++) {
-            qual_errors.push_back(QualErr(p.prof[r]));
+            qual_errors.push_back(std::make_shared<const QualErr>(p.prof[r]));
             ins_probs.push_back(p.ins_prob[r]);
             del_probs.push_back(p.del_prob[r]);
         }
@@ -369,6 +373,7 @@ struct IlluminaOneGenome {
         read_chrom_spaces.assign(ne, 0);
     }
 
+    void reset_quota() { chrom_reads.clear(); }
     // src/hts_illumina.h:410-418
     void add_n_reads(u64 n_reads, SeedSource& seeds) {
         std::vector<double> probs_(genome->chrom_sizes.begin(), genome->chrom_sizes.end());
@@ -453,7 +458,7 @@ struct IlluminaOneGenome {
                 rev_comp(read);
             }
             for (u64 b = 0; b < barcode.size(); b++) read[b] = barcode[b];
-            qual_errors[i].fill_read_qual(read, qual, insertions[i], deletions[i], eng);
+            qual_errors[i]->fill_read_qual(read, qual, insertions[i], deletions[i], eng);
             fill_fq_lines(pools[i], genome->name, genome->chrom_names[chrom_ind], read, qual, i, start,
                           paired, reverse);
         }
@@ -565,6 +570,7 @@ struct IlluminaHaplotypes {
         for (u64 i = 0; i < read_makers.size(); i++) read_makers[i].genome = &genomes[i];
     }
 
+    void reset_quota() { n_reads_vc.clear(); for (auto& rm : read_makers) rm.reset_quota(); }
     // src/hts_illumina.h:620-644
     void add_n_reads(u64 n_reads, SeedSource& seeds) {
         u64 n_haps = haps->size();
@@ -613,25 +619,47 @@ struct IlluminaHaplotypes {
 // restated for T sequential "threads".  Output = thread 0's pools, then thread 1's, ...
 // (one of the interleavings the reference's `omp critical` flush can produce).
 // -------------------------------------------------------------------------------------
+struct RunOpts {
+    u64 thread_begin = 0, thread_end = 0;   // only these threads generate (0,0 = all); seeds/quotas are
+                                            // still derived for every thread, so the kept ones are unchanged
+    bool discard = false;                   // count bytes only (null sink, for timing)
+    std::vector<std::vector<u64>> thread_bytes;   // out: [end][thread]
+};
+
 template <typename Filler>
 static void run_threads(const Filler& base, u64 n_reads, double prob_dup, u64 read_pool_size, u64 n_read_ends,
-                        u64 n_threads, SeedSource& seeds, std::vector<std::vector<char>>& files) {
+                        u64 n_threads, SeedSource& seeds, std::vector<std::vector<char>>& files, RunOpts& opts) {
     n_reads /= n_read_ends;
     std::vector<u64> reads_per_thread = split_int(n_reads, n_threads);
     for (u64& i : reads_per_thread) i *= n_read_ends;
     // mt_seeds first (src/hts.h:339), then one filler copy + add_n_reads per thread (:349-353)
     std::vector<const uint32_t*> tseeds(n_threads);
     for (u64 t = 0; t < n_threads; t++) tseeds[t] = seeds.take8();
+    // Threads outside the generation window only need their seed words consumed: run add_n_reads on one
+    // scratch copy for them instead of keeping a filler each.
+    const u64 tb = opts.thread_begin, te = opts.thread_end ? opts.thread_end : n_threads;
     std::vector<Filler> fillers;
-    fillers.reserve(n_threads);
+    fillers.reserve(te > tb ? te - tb : 0);
+    Filler scratch(base);
     for (u64 t = 0; t < n_threads; t++) {
-        fillers.push_back(base);
-        fillers.back().add_n_reads(reads_per_thread[t], seeds);
+        if (t >= tb && t < te) {
+            fillers.push_back(base);
+            fillers.back().add_n_reads(reads_per_thread[t], seeds);
+        } else {
+            scratch.reset_quota();
+            scratch.add_n_reads(reads_per_thread[t], seeds);
+        }
     }
     files.assign(n_read_ends, std::vector<char>());
-    for (u64 t = 0; t < n_threads; t++) {
+    // Threads are independent (own filler copy, own engine), so they may run concurrently; each
+    // keeps its own output and the pieces are concatenated in thread order afterwards.
+    std::vector<std::vector<std::vector<char>>> outs(te > tb ? te - tb : 0, std::vector<std::vector<char>>(n_read_ends));
+    opts.thread_bytes.assign(n_read_ends, std::vector<u64>(n_threads, 0));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (u64 t = tb; t < te; t++) {
+        std::vector<std::vector<char>>& files = outs[t - tb];
         Pcg64 eng = seeded_pcg(tseeds[t]);
-        Filler& filler = fillers[t];
+        Filler& filler = fillers[t - tb];
         const u64 n = reads_per_thread[t];
         u64 reads_made = 0, reads_in_pool = 0;
         std::vector<std::vector<char>> pools(n_read_ends);
@@ -654,11 +682,21 @@ static void run_threads(const Filler& base, u64 n_reads, double prob_dup, u64 re
             }
             if (do_write) {
                 for (u64 i = 0; i < pools.size(); i++) {
-                    files[i].insert(files[i].end(), pools[i].begin(), pools[i].end());
+                    opts.thread_bytes[i][t] += pools[i].size();
+                    if (!opts.discard) files[i].insert(files[i].end(), pools[i].begin(), pools[i].end());
                     pools[i].clear();
                 }
                 reads_in_pool = 0;
             }
+        }
+    }
+    for (u64 i = 0; i < n_read_ends; i++) {
+        size_t total = 0;
+        for (u64 t = 0; t < outs.size(); t++) total += outs[t][i].size();
+        files[i].reserve(total);
+        for (u64 t = 0; t < outs.size(); t++) {
+            files[i].insert(files[i].end(), outs[t][i].begin(), outs[t][i].end());
+            std::vector<char>().swap(outs[t][i]);
         }
     }
 }
@@ -694,6 +732,8 @@ using namespace orc;
 extern "C" {
 
 const char* orc_last_error(void) { return g_err.c_str(); }
+void orc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int orc_max_threads(void) { return omp_get_max_threads(); }
 void orc_free(void* p) { std::free(p); }
 
 void orc_pcg64_outputs(const uint32_t* sub_seeds, uint64_t n, uint64_t* out) {
@@ -789,7 +829,15 @@ struct orc_illumina_args {
     const uint32_t* n_quals1; const double* probs1; const uint8_t* quals1; double ins_prob1, del_prob1;
     const uint32_t* n_quals2; const double* probs2; const uint8_t* quals2; double ins_prob2, del_prob2;
     const uint32_t* seed_words; uint64_t n_seed_words;
+    uint64_t thread_begin, thread_end;   // generate only these threads (0,0 = all)
+    int32_t discard;                     // 1 = null sink (bytes are counted, not kept)
+    uint64_t* thread_bytes1; uint64_t* thread_bytes2;   // optional out: [n_threads] bytes per thread and end
 };
+
+static void export_thread_bytes(const orc_illumina_args* a, const RunOpts& o) {
+    if (a->thread_bytes1) for (u64 t = 0; t < a->n_threads; t++) a->thread_bytes1[t] = o.thread_bytes[0][t];
+    if (a->thread_bytes2 && a->paired) for (u64 t = 0; t < a->n_threads; t++) a->thread_bytes2[t] = o.thread_bytes[1][t];
+}
 
 static IlluminaParams to_params(const orc_illumina_args* a) {
     IlluminaParams p;
@@ -823,7 +871,9 @@ int orc_illumina_ref(uint64_t n_chroms, const char* const* chrom_names, const ch
         IlluminaOneGenome base(g, p, barcode ? barcode : "");
         SeedSource seeds{a->seed_words, a->n_seed_words, 0};
         std::vector<std::vector<char>> files;
-        run_threads(base, a->n_reads, a->prob_dup, a->read_pool_size, a->paired ? 2 : 1, a->n_threads, seeds, files);
+        RunOpts opts; opts.thread_begin = a->thread_begin; opts.thread_end = a->thread_end; opts.discard = a->discard != 0;
+        run_threads(base, a->n_reads, a->prob_dup, a->read_pool_size, a->paired ? 2 : 1, a->n_threads, seeds, files, opts);
+        export_thread_bytes(a, opts);
         give(files[0], out1, len1);
         if (a->paired) give(files[1], out2, len2); else { *out2 = nullptr; *len2 = 0; }
         if (seed_words_used) *seed_words_used = seeds.pos;
@@ -887,7 +937,9 @@ int orc_illumina_hap(const orc_hap_set* hs, const double* hap_probs, const orc_i
         IlluminaHaplotypes base(haps, std::vector<double>(hap_probs, hap_probs + hs->n_haps), p, bcs);
         SeedSource seeds{a->seed_words, a->n_seed_words, 0};
         std::vector<std::vector<char>> files;
-        run_threads(base, a->n_reads, a->prob_dup, a->read_pool_size, a->paired ? 2 : 1, a->n_threads, seeds, files);
+        RunOpts opts; opts.thread_begin = a->thread_begin; opts.thread_end = a->thread_end; opts.discard = a->discard != 0;
+        run_threads(base, a->n_reads, a->prob_dup, a->read_pool_size, a->paired ? 2 : 1, a->n_threads, seeds, files, opts);
+        export_thread_bytes(a, opts);
         give(files[0], out1, len1);
         if (a->paired) give(files[1], out2, len2); else { *out2 = nullptr; *len2 = 0; }
         if (seed_words_used) *seed_words_used = seeds.pos;

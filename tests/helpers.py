@@ -1,0 +1,71 @@
+"""Shared helpers for the parity tests: one place that runs the same job through the oracle and
+through the HIP path (via the C ABI), so the individual tests read like the reference's own."""
+import numpy as np
+
+DEFAULTS = dict(paired=True, matepair=False, prob_dup=0.02, read_pool_size=1000, frag_mean=400.0, frag_sd=100.0,
+                frag_len_min=None, frag_len_max=None, ins_prob1=0.00009, del_prob1=0.00011, ins_prob2=0.00015,
+                del_prob2=0.00023, barcode="")
+
+
+def job(**kw):
+    d = dict(DEFAULTS)
+    d.update(kw)
+    return d
+
+
+def run_oracle(O, genome, prof1, prof2, words, n_reads, n_threads, j, **extra):
+    L = prof1.read_length
+    fmin = j["frag_len_min"] if j["frag_len_min"] is not None else L
+    fmax = j["frag_len_max"] if j["frag_len_max"] is not None else 2 ** 32 - 1
+    shape = (j["frag_mean"] / j["frag_sd"]) ** 2
+    scale = j["frag_sd"] ** 2 / j["frag_mean"]
+    paired = j["paired"] or j["matepair"]
+    return O.illumina_ref(genome, paired=paired, matepair=j["matepair"], n_reads=n_reads, prob_dup=j["prob_dup"],
+                          n_threads=n_threads, read_pool_size=j["read_pool_size"], shape=shape, scale=scale,
+                          fmin=fmin, fmax=fmax, prof1=prof1, prof2=prof2, ins1=j["ins_prob1"], del1=j["del_prob1"],
+                          ins2=j["ins_prob2"], del2=j["del_prob2"], barcode=j["barcode"], words=words, **extra)
+
+
+def open_hip(ja, genome, profile_files, read_length, words, n_reads, n_threads, j, **extra):
+    """illumina(..., _session=True) through the package's R-level mirror."""
+    p1, p2 = profile_files
+    return ja.illumina(genome, None, n_reads, read_length, j["paired"], frag_mean=j["frag_mean"], frag_sd=j["frag_sd"],
+                       matepair=j["matepair"], profile1=p1, profile2=p2, ins_prob1=j["ins_prob1"],
+                       del_prob1=j["del_prob1"], ins_prob2=j["ins_prob2"], del_prob2=j["del_prob2"],
+                       frag_len_min=j["frag_len_min"], frag_len_max=j["frag_len_max"],
+                       barcodes=j["barcode"] if j["barcode"] else None, prob_dup=j["prob_dup"], n_threads=n_threads,
+                       read_pool_size=j["read_pool_size"], seed_words=words, _session=True, **extra)
+
+
+def run_hip(ja, genome, profile_files, read_length, words, n_reads, n_threads, j, **extra):
+    with open_hip(ja, genome, profile_files, read_length, words, n_reads, n_threads, j, **extra) as s:
+        s.generate()
+        sizes, reads = s.sizes()
+        r1 = s.fetch(0)
+        r2 = s.fetch(1) if len(sizes) > 1 else None
+        return r1, r2, reads, s.seed_words_used()
+
+
+def fastq_records(data):
+    lines = data.split(b"\n")
+    assert lines[-1] == b""
+    lines = lines[:-1]
+    assert len(lines) % 4 == 0
+    return [(lines[i], lines[i + 1], lines[i + 2], lines[i + 3]) for i in range(0, len(lines), 4)]
+
+
+def write_test_profile(path, n_pos=100, qual=255, count=1000):
+    """The one-quality profile of the reference's known-answer tests (test-sequencer.R:82-87)."""
+    with open(path, "w") as fh:
+        for nt in "ACGT":          # the R code orders rows by nucleotide name
+            for pos in range(n_pos):
+                fh.write("%s\t%d\t%d\n" % (nt, pos, qual))
+                fh.write("%s\t%d\t%d\n" % (nt, pos, count))
+    return path
+
+
+def first_diff(a, b):
+    n = min(len(a), len(b))
+    x = np.frombuffer(a[:n], dtype=np.uint8) != np.frombuffer(b[:n], dtype=np.uint8)
+    idx = int(np.argmax(x)) if x.any() else n
+    return idx, a[max(0, idx - 80):idx + 80], b[max(0, idx - 80):idx + 80]

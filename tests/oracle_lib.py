@@ -20,7 +20,9 @@ class OrcIlluminaArgs(C.Structure):
                 ("ins_prob1", C.c_double), ("del_prob1", C.c_double),
                 ("n_quals2", C.c_void_p), ("probs2", C.c_void_p), ("quals2", C.c_void_p),
                 ("ins_prob2", C.c_double), ("del_prob2", C.c_double),
-                ("seed_words", C.c_void_p), ("n_seed_words", C.c_uint64)]
+                ("seed_words", C.c_void_p), ("n_seed_words", C.c_uint64),
+                ("thread_begin", C.c_uint64), ("thread_end", C.c_uint64), ("discard", C.c_int32),
+                ("thread_bytes1", C.c_void_p), ("thread_bytes2", C.c_void_p)]
 
 
 class OrcHapSet(C.Structure):
@@ -129,10 +131,20 @@ def _args(paired, matepair, n_reads, prob_dup, n_threads, read_pool_size, shape,
 
 
 def illumina_ref(genome, *, paired, matepair=False, n_reads, prob_dup, n_threads, read_pool_size, shape, scale, fmin,
-                 fmax, prof1, prof2=None, ins1, del1, ins2=0.0, del2=0.0, barcode="", words):
-    """Oracle run of illumina_ref_cpp; returns (fastq_R1 bytes, fastq_R2 bytes or None, seed words used)."""
+                 fmax, prof1, prof2=None, ins1, del1, ins2=0.0, del2=0.0, barcode="", words,
+                 thread_begin=0, thread_end=0, discard=False, thread_bytes=None):
+    """Oracle run of illumina_ref_cpp; returns (fastq_R1 bytes, fastq_R2 bytes or None, seed words used).
+
+    thread_begin/thread_end restrict generation to a window of threads (all seeds/quotas are still
+    derived); discard=True keeps no FASTQ (timing); thread_bytes = dict that receives per-thread byte
+    counts as numpy arrays under keys 0 and 1."""
     a, keep = _args(paired, matepair, n_reads, prob_dup, n_threads, read_pool_size, shape, scale, fmin, fmax, prof1,
                     prof2, ins1, del1, ins2, del2, words)
+    a.thread_begin, a.thread_end, a.discard = int(thread_begin), int(thread_end), int(bool(discard))
+    tb = [np.zeros(int(n_threads), dtype=np.uint64), np.zeros(int(n_threads), dtype=np.uint64)]
+    a.thread_bytes1, a.thread_bytes2 = tb[0].ctypes.data, tb[1].ctypes.data
+    if thread_bytes is not None:
+        thread_bytes[0], thread_bytes[1] = tb[0], tb[1]
     n = genome.n_chroms()
     names = (C.c_char_p * n)(*[x.encode() for x in genome.names])
     seqs = (C.c_void_p * n)(*[s.ctypes.data for s in genome.seqs])

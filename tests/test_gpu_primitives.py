@@ -1,0 +1,64 @@
+"""GPU: every arithmetic primitive of the path evaluated ON THE DEVICE (jk_dev_eval runs the same
+inline functions the kernels use, one thread per element) against the oracle, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from jackalope_amd import _abi
+from test_host_primitives import raw_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_eval(what, xs, aux=0):
+    xs = np.ascontiguousarray(xs, dtype=np.uint64)
+    stream = what in (_abi.OP_PCG_STREAM, _abi.OP_GAMMA_STREAM)
+    n = xs.size // 8 if stream else xs.size
+    out = np.zeros(n * aux if stream else n, dtype=np.uint64)
+    _abi.check(_abi.lib().jk_dev_eval(0, what, xs.ctypes.data, n, aux, out.ctypes.data))
+    return out
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 10, 41, 255])
+def test_runif_index(O, built, n):
+    x = raw_inputs(1_000_000, seed=100 + n)
+    assert (dev_eval(_abi.OP_RUNIF_INDEX, x, n) == O.eval_many(_abi.OP_RUNIF_INDEX, x, n)).all()
+
+
+@pytest.mark.parametrize("what", [_abi.OP_RUNIF_DOUBLE, _abi.OP_CANONICAL, _abi.OP_N_QUAL, _abi.OP_LT_HALF])
+def test_unary_conversions(O, built, what):
+    x = raw_inputs(4_000_000, seed=200 + what)
+    assert (dev_eval(what, x) == O.eval_many(what, x)).all()
+
+
+@pytest.mark.parametrize("span", [1, 3, 1000, 99_999_851, 2 ** 32, 3 * 10 ** 9])
+def test_frag_start(O, built, span):
+    x = raw_inputs(1_000_000, seed=span % 1000)
+    assert (dev_eval(_abi.OP_FRAG_START, x, span) == O.eval_many(_abi.OP_FRAG_START, x, span)).all()
+
+
+def test_log_and_sqrt_match_host_libm(O, built):
+    rng = np.random.default_rng(12)
+    n = 4_000_000
+    d = np.concatenate([rng.random(n), 1 + (rng.random(n) - 0.5) * 0.13, rng.random(n) * 1e-300,
+                        np.exp(rng.normal(0, 50, n)), np.array([1.0, 0.5, 2.0, 1e-310, 5e-324, np.inf])])
+    bits = d.astype(np.float64).view(np.uint64)
+    assert (dev_eval(_abi.OP_LOG, bits) == O.eval_many(_abi.OP_LOG, bits)).all()
+    assert (dev_eval(_abi.OP_SQRT, bits) == O.eval_many(_abi.OP_SQRT, bits)).all()
+
+
+def test_pcg_and_gamma_streams(O, built):
+    rng = np.random.default_rng(6)
+    sw = rng.integers(0, 2 ** 32, size=8 * 4096, dtype=np.uint64)
+    assert (dev_eval(_abi.OP_PCG_STREAM, sw, 128) == O.eval_many(_abi.OP_PCG_STREAM, sw, 128)).all()
+    O.lib().orc_gamma_streams.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    for shape, scale in [(16.0, 25.0), (1.0, 300.0), (2.5, 7.0)]:
+        _abi.lib().jk_eval_set_gamma(shape, scale)
+        O.lib().orc_set_gamma(C.c_double(shape), C.c_double(scale))
+        g1 = dev_eval(_abi.OP_GAMMA_STREAM, sw, 200)
+        g2 = np.zeros(4096 * 200, dtype=np.uint64)
+        O.lib().orc_gamma_streams(sw.ctypes.data, 4096, 200, g2.ctypes.data)
+        assert (g1 == g2).all(), (shape, scale)
+    _abi.lib().jk_eval_set_gamma(16.0, 25.0)
+    O.lib().orc_set_gamma(C.c_double(16.0), C.c_double(25.0))

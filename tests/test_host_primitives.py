@@ -1,0 +1,123 @@
+"""CPU-only: the arithmetic the kernels run (csrc/jk_math.h) evaluated on the host through the C ABI
+and compared bit for bit with the oracle's x87 / libstdc++ / glibc expressions."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from jackalope_amd import _abi
+
+
+def host_eval(what, xs, aux=0):
+    xs = np.ascontiguousarray(xs, dtype=np.uint64)
+    stream = what in (_abi.OP_PCG_STREAM, _abi.OP_GAMMA_STREAM)
+    n = xs.size // 8 if stream else xs.size
+    out = np.zeros(n * aux if stream else n, dtype=np.uint64)
+    _abi.check(_abi.lib().jk_host_eval(what, xs.ctypes.data, n, aux, out.ctypes.data))
+    return out
+
+
+def raw_inputs(n, seed=1):
+    rng = np.random.default_rng(seed)
+    xs = rng.integers(0, 2 ** 64, size=n, dtype=np.uint64)
+    edge = [0, 1, 2, 2 ** 63 - 2, 2 ** 63 - 1, 2 ** 63, 2 ** 64 - 1, 2 ** 64 - 2, 2 ** 64 - 1024, 2 ** 64 - 1025,
+            2 ** 64 - 2048, 2 ** 53, 2 ** 53 + 1, 2 ** 32, 2 ** 32 - 1]
+    adv = []
+    for n_ in [3, 5, 6, 7, 8, 10, 4, 33, 100, 255]:      # products just around k * 2^64
+        for k in range(1, n_ + 1):
+            t = (k << 64) // n_
+            adv += [v for v in (t + d - 1 for d in range(-3, 4)) if 0 <= v < 2 ** 64]
+    return np.concatenate([xs, np.array(edge, dtype=np.uint64), np.array(adv, dtype=np.uint64)])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 10, 33, 41, 100, 255])
+def test_runif_index(O, built, n):
+    x = raw_inputs(300_000, seed=n)
+    assert (host_eval(_abi.OP_RUNIF_INDEX, x, n) == O.eval_many(_abi.OP_RUNIF_INDEX, x, n)).all()
+
+
+@pytest.mark.parametrize("what", [_abi.OP_RUNIF_DOUBLE, _abi.OP_CANONICAL, _abi.OP_N_QUAL, _abi.OP_LT_HALF])
+def test_unary_conversions(O, built, what):
+    x = raw_inputs(1_000_000, seed=what)
+    assert (host_eval(what, x) == O.eval_many(what, x)).all()
+
+
+@pytest.mark.parametrize("span", [1, 2, 3, 1000, 99_999_851, 2 ** 32, 3 * 10 ** 9])
+def test_frag_start(O, built, span):
+    x = raw_inputs(200_000, seed=span % 1000)
+    assert (host_eval(_abi.OP_FRAG_START, x, span) == O.eval_many(_abi.OP_FRAG_START, x, span)).all()
+
+
+def test_log_is_glibc_log(O, built):
+    """jk_log restates glibc 2.35's log (FMA variant); std::gamma_distribution calls it."""
+    rng = np.random.default_rng(11)
+    n = 1_000_000
+    d = np.concatenate([rng.random(n), 1 + (rng.random(n) - 0.5) * 0.13, rng.random(n) * 1e-300,
+                        np.exp(rng.normal(0, 50, n)), np.array([1.0, 0.5, 2.0, 1e-310, 5e-324, np.inf, 0.0])])
+    bits = d.astype(np.float64).view(np.uint64)
+    a, b = host_eval(_abi.OP_LOG, bits), O.eval_many(_abi.OP_LOG, bits)
+    assert (a == b).all(), "jk_log differs from this host's libm log on %d inputs" % int((a != b).sum())
+
+
+def test_pcg_and_gamma_streams(O, built):
+    rng = np.random.default_rng(5)
+    sw = rng.integers(0, 2 ** 32, size=8 * 500, dtype=np.uint64)
+    assert (host_eval(_abi.OP_PCG_STREAM, sw, 64) == O.eval_many(_abi.OP_PCG_STREAM, sw, 64)).all()
+    for shape, scale in [(16.0, 25.0), (1.0, 300.0), (2.5, 7.0), (100.0, 4.0)]:
+        _abi.lib().jk_eval_set_gamma(shape, scale)
+        O.lib().orc_set_gamma(C.c_double(shape), C.c_double(scale))
+        O.lib().orc_gamma_streams.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+        g1 = host_eval(_abi.OP_GAMMA_STREAM, sw, 100)
+        g2 = np.zeros(500 * 100, dtype=np.uint64)
+        O.lib().orc_gamma_streams(sw.ctypes.data, 500, 100, g2.ctypes.data)
+        assert (g1 == g2).all(), (shape, scale)
+    _abi.lib().jk_eval_set_gamma(16.0, 25.0)
+    O.lib().orc_set_gamma(C.c_double(16.0), C.c_double(25.0))
+
+
+def test_alias_tables(O, built, hs25):
+    L = _abi.lib()
+    rng = np.random.default_rng(2)
+    cases = [rng.random(k) for k in (1, 2, 3, 5, 8, 17, 40)] + [np.array([1.0]), np.array([0.5, 0.5]),
+                                                                 np.array([1e-9, 1.0, 1e-9])]
+    off = 0
+    p = hs25[0]
+    for k in p.n_quals.ravel()[:400]:            # real profile rows too
+        cases.append(p.probs[off:off + k])
+        off += k
+    for probs in cases:
+        probs = np.ascontiguousarray(probs, dtype=np.float64)
+        P, A = np.zeros(probs.size), np.zeros(probs.size, dtype=np.uint64)
+        L.jk_alias_build(probs.ctypes.data, probs.size, P.ctypes.data, A.ctypes.data)
+        P2, A2 = O.alias_build(probs)
+        assert (P.view(np.uint64) == P2.view(np.uint64)).all()
+        # Alias[] is only meaningful where Prob < 1
+        m = P < 1
+        assert (A[m] == A2[m]).all()
+
+
+def test_split_int_and_reads_per_group(O, built, ja):
+    L = _abi.lib()
+    for x, n in [(0, 1), (10, 3), (10_000_000, 1 << 20), (7, 7), (5, 9)]:
+        a, b = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        L.jk_split_int(x, n, a.ctypes.data)
+        O.lib().orc_split_int(C.c_uint64(x), C.c_uint64(n), b.ctypes.data_as(C.c_void_p))
+        assert (a == b).all() and int(a.sum()) == x
+    rng = np.random.default_rng(9)
+    for n_reads in (0, 1, 7, 1000, 10 ** 6, 10 ** 9):
+        for G in (1, 2, 5, 24):
+            probs = rng.random(G) * 1e8
+            if G > 2:
+                probs[1] = 0.0
+            words = ja.seed_words(n_reads + G, 64)
+            out1, out2 = np.zeros(G, dtype=np.uint64), np.zeros(G, dtype=np.uint64)
+            src = _abi.SeedSource()
+            src.words = words.ctypes.data_as(C.POINTER(C.c_uint32))
+            src.n_words = words.size
+            _abi.check(L.jk_reads_per_group(n_reads, probs.ctypes.data, G, C.byref(src), out1.ctypes.data))
+            used = C.c_uint64()
+            rc = O.lib().orc_reads_per_group(C.c_uint64(n_reads), probs.ctypes.data_as(C.c_void_p), C.c_uint64(G),
+                                             words.ctypes.data_as(C.c_void_p), C.c_uint64(words.size),
+                                             out2.ctypes.data_as(C.c_void_p), C.byref(used))
+            assert rc == 0 and (out1 == out2).all() and int(out1.sum()) == n_reads
+            assert words.size - src.n_words == used.value == (8 if n_reads > 0 else 0)

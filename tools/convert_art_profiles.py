@@ -20,9 +20,7 @@ import sys
 import numpy as np
 
 DEFAULT_SRC = "/root/reference/inst/art_profiles"
-DEFAULT_NAMES = ["HiSeq2500L150R1filter", "HiSeq2500L150R2filter",
-                 "HiSeq2000L100R1", "HiSeq2000L100R2",
-                 "EmpMiSeq250R1", "EmpMiSeq250R2"]
+DEFAULT_NAMES = None   # None = every *.txt.gz in SRC_DIR
 
 
 def _as_count(x):
@@ -65,7 +63,7 @@ def parse(path):
 
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else DEFAULT_SRC
-    names = sys.argv[2:] or DEFAULT_NAMES
+    names = sys.argv[2:] or DEFAULT_NAMES or sorted(f[:-7] for f in os.listdir(src) if f.endswith(".txt.gz"))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                            "jackalope_amd", "data", "art_profiles")
     os.makedirs(out_dir, exist_ok=True)
