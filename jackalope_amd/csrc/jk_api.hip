@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -72,6 +73,7 @@ struct jk_session {
     DevBuf d_info, d_thresh, d_quals, d_mm;
     bool lds_tables = false;
     size_t lds_bytes = 0;
+    int block = 1024;          // generator workgroup size (JK_BLOCK=512 selects the 256-VGPR variant)
     // lanes of this shard
     uint64_t n_lanes_total = 0, lane_begin = 0, lane_end = 0, n_shard = 0;
     std::vector<uint64_t> pool_off_host;          // per batch-relative offsets, concatenated per batch (n+1 each)
@@ -204,7 +206,9 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
     const uint64_t rec_max = max_hdr + n_digits(max_chrom) + 2 + (s.paired ? 2 : 0) + 1 + (uint64_t)L + 3 + L + 1;
     const uint64_t max_batch = a.max_batch_bytes ? a.max_batch_bytes : (8ULL << 30);
     const uint64_t max_batch_lanes = 1ULL << 22;
-    std::vector<uint64_t> pool_off;    // concatenation over batches of (n_lanes+1) relative offsets
+    // Pools are organised in tiles of 64 lanes (one wave); every lane of a tile gets the capacity of
+    // the tile's largest quota.  A batch is a run of whole tiles.
+    std::vector<uint64_t> pool_off;    // concatenation over batches of (n_tiles+1) relative offsets
     uint64_t out_cap = 0, max_pool = 0;
     uint32_t max_lanes = 0;
     {
@@ -215,9 +219,12 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
             pool_off.push_back(0);
             uint64_t used = 0;
             while (l < s.n_shard && b.n_lanes < max_batch_lanes) {
-                const uint64_t cap = align_up((lane_reads[l] / s.n_ends) * rec_max, 16);
+                const uint64_t tl = std::min<uint64_t>(64, s.n_shard - l);
+                uint64_t maxq = 0;
+                for (uint64_t k = 0; k < tl; k++) maxq = std::max(maxq, lane_reads[l + k] / s.n_ends);
+                const uint64_t cap = align_up(maxq * rec_max, 4) * 64;
                 if (b.n_lanes > 0 && used + cap > max_batch) break;
-                used += cap; pool_off.push_back(used); b.n_lanes++; l++;
+                used += cap; pool_off.push_back(used); b.n_lanes += (uint32_t)tl; l += tl;
             }
             b.pool_bytes = used;
             out_cap += used;
@@ -294,9 +301,12 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
     s.events.resize(n_ev);
     for (hipEvent_t& e : s.events) JK_HIP(hipEventCreate(&e));
 
+    if (const char* e = std::getenv("JK_BLOCK")) s.block = std::atoi(e) == 512 ? 512 : 1024;
     if (s.lds_tables) {
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 1, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
     }
 }
 
@@ -323,16 +333,18 @@ static void launch_generate(jk_session& s) {
         }
         P.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
         P.chrom_stride = (uint32_t)s.n_shard;
-        const uint32_t block = 1024;
+        const uint32_t block = (uint32_t)s.block;
         const uint32_t grid = (B.n_lanes + block - 1) / block;
         JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+#define JK_LAUNCH(LDS, NE, BLK, SH) hipLaunchKernelGGL((illumina_ref_kernel<LDS, NE, BLK>), dim3(grid), dim3(block), SH, s.stream, P)
         if (s.lds_tables) {
-            if (s.n_ends == 2) hipLaunchKernelGGL((illumina_ref_kernel<true, 2>), dim3(grid), dim3(block), s.lds_bytes, s.stream, P);
-            else hipLaunchKernelGGL((illumina_ref_kernel<true, 1>), dim3(grid), dim3(block), s.lds_bytes, s.stream, P);
+            if (block == 1024) { if (s.n_ends == 2) JK_LAUNCH(true, 2, 1024, s.lds_bytes); else JK_LAUNCH(true, 1, 1024, s.lds_bytes); }
+            else               { if (s.n_ends == 2) JK_LAUNCH(true, 2, 512, s.lds_bytes);  else JK_LAUNCH(true, 1, 512, s.lds_bytes); }
         } else {
-            if (s.n_ends == 2) hipLaunchKernelGGL((illumina_ref_kernel<false, 2>), dim3(grid), dim3(block), 0, s.stream, P);
-            else hipLaunchKernelGGL((illumina_ref_kernel<false, 1>), dim3(grid), dim3(block), 0, s.stream, P);
+            if (block == 1024) { if (s.n_ends == 2) JK_LAUNCH(false, 2, 1024, 0); else JK_LAUNCH(false, 1, 1024, 0); }
+            else               { if (s.n_ends == 2) JK_LAUNCH(false, 2, 512, 0);  else JK_LAUNCH(false, 1, 512, 0); }
         }
+#undef JK_LAUNCH
         JK_HIP(hipGetLastError());
         JK_HIP(hipEventRecord(s.events[ev++], s.stream));
         const uint32_t nb = (B.n_lanes + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -344,7 +356,7 @@ static void launch_generate(jk_session& s) {
             hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s.stream, lb, lo, bs, B.n_lanes);
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.stream, bs, nb, base);
             hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s.stream, lo, bs, B.n_lanes);
-            hipLaunchKernelGGL(compact_pools_kernel, dim3((B.n_lanes + 3) / 4), dim3(256), 0, s.stream,
+            hipLaunchKernelGGL(compact_pools_kernel, dim3((B.n_lanes + 63) / 64), dim3(256), 0, s.stream,
                                s.d_pool[e].as<uint8_t>(), P.pool_off, lb, lo, s.d_out[e].as<uint8_t>(), base, B.n_lanes);
             JK_HIP(hipGetLastError());
         }

@@ -13,6 +13,13 @@
 // branches.  The kernel is bound by the 128-bit pcg64 multiply (about 1200 draws per read pair),
 // not by HBM: per pair it reads 300 reference bytes and writes ~660 FASTQ bytes.
 //
+// Pool layout (chosen from the first rocprof PMC pass, profiles/r01_v1_*: a pool region per lane
+// with 4-byte stores cost 8x write amplification and byte-wise reference loads missed L2 for most
+// bases): lanes are grouped in tiles of 64 (= one wave) and a tile's pools are word-interleaved,
+// word k of lane l at tile_base + (k*64 + l)*4, so that the 64 lanes of a wave, which emit their
+// k-th word at (nearly) the same time, store one contiguous 256-byte row.  The reference is read in
+// aligned 8-byte pieces kept in a register pair.
+//
 // Memory plan per workgroup: the ART quality tables (alias thresholds as exact u64 cut points on
 // the raw pcg output, qualities, mismatch cut points) are staged once into LDS (97.5 KB for the
 // HiSeq 2500 / 150 bp pair of profiles -> one 1024-thread workgroup per CU, 4 waves per SIMD);
@@ -48,7 +55,7 @@ struct IlluminaKernelParams {
     const uint64_t* lane_reads;  // [n_lanes] read quota (all ends)
     const uint32_t* chrom_reads; // per-chromosome read quotas, chromosome-major: [ci * chrom_stride + lane]
     uint32_t chrom_stride;
-    const uint64_t* pool_off;    // [n_lanes + 1] byte offset of each lane's pool region (same for every end)
+    const uint64_t* pool_off;    // [n_tiles + 1] byte offset of each 64-lane tile's pools (same for every end)
     uint8_t* pool[2];            // pool buffers, one per read end
     uint64_t* lane_bytes[2];     // out: bytes written per lane and end
     uint64_t* lane_made;         // out: reads made per lane
@@ -70,35 +77,40 @@ struct IlluminaKernelParams {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Byte appender into a lane's pool region.  Bytes are gathered into a 32-bit word and stored
-// when the word is complete; the first (partial) word of a stream that starts mid-word is written
-// byte by byte because its low bytes belong to whoever wrote before.
+// Byte appender into a lane's pool (one column of its tile).  Bytes are gathered into a 32-bit word
+// and stored when the word is complete; the first (partial) word of a stream that starts mid-word is
+// written byte by byte because its low bytes belong to whoever wrote before.
 // ---------------------------------------------------------------------------------------------
 struct OutStream {
-    uint8_t* p;        // address of the next byte
+    uint8_t* wp;       // address of the current word (this lane's column of the tile)
+    uint32_t pos;      // byte offset in the lane's stream
     uint32_t w;        // bytes gathered for the current word
     uint32_t head;     // 1 while the current word started mid-word
 };
 
-__device__ __forceinline__ void os_begin(OutStream& s, uint8_t* p) {
-    s.p = p; s.w = 0; s.head = (((uintptr_t)p) & 3u) ? 1u : 0u;
+constexpr uint32_t TILE_ROW = 64 * 4;      // bytes between consecutive words of one lane
+
+__device__ __forceinline__ void os_begin(OutStream& s, uint8_t* lane_base, uint32_t pos) {
+    s.wp = lane_base + (size_t)(pos >> 2) * TILE_ROW;
+    s.pos = pos; s.w = 0; s.head = (pos & 3u) ? 1u : 0u;
 }
 __device__ __forceinline__ void os_put(OutStream& s, uint32_t byte) {
-    const uint32_t k = (uint32_t)((uintptr_t)s.p) & 3u;
+    const uint32_t k = s.pos & 3u;
     if (s.head) {
-        *s.p = (uint8_t)byte;
+        s.wp[k] = (uint8_t)byte;
         if (k == 3u) s.head = 0;
     } else {
         s.w |= byte << (8u * k);
-        if (k == 3u) { *reinterpret_cast<uint32_t*>(s.p - 3) = s.w; s.w = 0; }
+        if (k == 3u) { *reinterpret_cast<uint32_t*>(s.wp) = s.w; s.w = 0; }
     }
-    s.p++;
+    if (k == 3u) s.wp += TILE_ROW;
+    s.pos++;
 }
 // write out whatever is pending in the current word (as bytes); the stream can be abandoned after
 __device__ __forceinline__ void os_flush(OutStream& s) {
-    const uint32_t k = (uint32_t)((uintptr_t)s.p) & 3u;
+    const uint32_t k = s.pos & 3u;
     if (!s.head) {
-        for (uint32_t j = 0; j < k; j++) *(s.p - k + j) = (uint8_t)(s.w >> (8u * j));
+        for (uint32_t j = 0; j < k; j++) s.wp[j] = (uint8_t)(s.w >> (8u * j));
     }
     s.w = 0;
     s.head = k ? 1u : 0u;     // if anything more is appended it continues this (already written) word
@@ -123,8 +135,10 @@ struct TabPtrs {
     const uint32_t* info; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm;
 };
 
-template <bool LDS_TAB, uint32_t NE>      // NE = number of read ends (1 single-end, 2 paired)
-__global__ void __launch_bounds__(1024)
+// NE = number of read ends (1 single-end, 2 paired); BLOCK = workgroup size (1024 -> 4 waves/SIMD and a
+// 128-VGPR budget, 512 -> 2 waves/SIMD and 256 VGPRs; with the tables in LDS one workgroup fits per CU)
+template <bool LDS_TAB, uint32_t NE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 illumina_ref_kernel(IlluminaKernelParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     TabPtrs T;
@@ -158,11 +172,14 @@ illumina_ref_kernel(IlluminaKernelParams P) {
     uint32_t ci = 0;
     uint64_t ccnt = P.g.n_chroms ? P.chrom_reads[lane] : 0;
 
-    uint8_t* const base0 = P.pool[0] + P.pool_off[lane];
-    uint8_t* const base1 = NE > 1 ? P.pool[1] + P.pool_off[lane] : nullptr;
+    const uint32_t tile = lane >> 6;
+    const uint64_t tile_off = P.pool_off[tile];
+    const uint64_t lane_cap = (P.pool_off[tile + 1] - tile_off) >> 6;     // bytes per lane in this tile
+    uint8_t* const base0 = P.pool[0] + tile_off + (lane & 63u) * 4u;
+    uint8_t* const base1 = NE > 1 ? P.pool[1] + tile_off + (lane & 63u) * 4u : nullptr;
     OutStream os[2];
-    os_begin(os[0], base0);
-    os_begin(os[1], base1);     // unused when NE == 1
+    os_begin(os[0], base0, 0);
+    os_begin(os[1], base1, 0);     // unused when NE == 1
 
     uint64_t frag_len = 0, frag_start = 0;
     uint32_t err = 0;
@@ -279,11 +296,13 @@ illumina_ref_kernel(IlluminaKernelParams P) {
             // the quality line is produced in the same pass as the bases, by its own stream that
             // starts right after the bases with "\n+\n"
             OutStream oq;
-            os_begin(oq, o.p + n_out);
+            os_begin(oq, i == 0 ? base0 : base1, o.pos + n_out);
             os_put(oq, '\n'); os_put(oq, '+'); os_put(oq, '\n');
 
             // ---- bases + qualities (fill_read / rev_comp / fill_read_qual)
-            const uint8_t* chrom = P.g.seq + P.g.chrom_off[ci];
+            const uint64_t chrom_base = P.g.chrom_off[ci];
+            uint64_t gbuf = 0;
+            uint32_t gchunk = ~(uint32_t)((chrom_base + (reverse ? (start + sp - 1 - bc) : start)) >> 3);   // != first chunk
             // source position pp of the (pre-indel) read: pp < bc barcode; else forward chrom[start + pp - bc],
             // reverse: complement of chrom[start + sp - 1 - pp]
             uint64_t gpos = reverse ? (start + sp - 1 - bc) : start;
@@ -303,7 +322,13 @@ illumina_ref_kernel(IlluminaKernelParams P) {
                         const bool deleted = em && ((dw >> bit) & 1ULL);
                         if (!deleted) {
                             if (pp < bc) c = P.barcode[pp];
-                            else { c = chrom[gpos]; if (reverse) c = cmp_base(c); }
+                            else {
+                                const uint64_t a = chrom_base + gpos;
+                                const uint32_t ch = (uint32_t)(a >> 3);
+                                if (ch != gchunk) { gbuf = *reinterpret_cast<const uint64_t*>(P.g.seq + ((a >> 3) << 3)); gchunk = ch; }
+                                c = (uint32_t)(gbuf >> (((uint32_t)a & 7u) * 8u)) & 0xffu;
+                                if (reverse) c = cmp_base(c);
+                            }
                             if (em && ((iw >> bit) & 1ULL)) {
                                 pending = true;
                                 pend_base = (uint32_t)((b0w >> bit) & 1ULL) | ((uint32_t)((b1w >> bit) & 1ULL) << 1);
@@ -368,35 +393,70 @@ illumina_ref_kernel(IlluminaKernelParams P) {
 #pragma unroll
     for (uint32_t i = 0; i < NE; i++) {
         os_flush(os[i]);
-        const uint64_t nbytes = (uint64_t)(os[i].p - (i == 0 ? base0 : base1));
+        const uint64_t nbytes = os[i].pos;
         P.lane_bytes[i][lane] = nbytes;
-        if (nbytes > P.pool_off[lane + 1] - P.pool_off[lane]) err |= JK_KERR_POOL_OVERFLOW;
+        if (nbytes > lane_cap) err |= JK_KERR_POOL_OVERFLOW;
     }
     P.lane_made[lane] = made;
     if (err) atomicOr(P.err, err);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pool compaction: lane-major FASTQ image.  One wave per lane copies that lane's pool region
-// (16-B aligned source) to its final offset (arbitrary alignment) in 16-B pieces.
+// Pool compaction: word-interleaved tiles -> lane-major FASTQ image.  One 256-thread workgroup per
+// 64-lane tile.  Per step it moves 32 words (128 B) of every lane: rows of the tile are read
+// coalesced into LDS (row stride 65 words: the transposed reads below are then conflict-free), and
+// each lane's 128 bytes are written by 8 consecutive threads as 16-byte pieces at the lane's final
+// offset (arbitrary alignment; unaligned dwordx4 stores are legal on gfx950 global memory).
 // ---------------------------------------------------------------------------------------------
+constexpr int CP_ROWS = 32;
 __global__ void __launch_bounds__(256)
 compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
                      const uint64_t* __restrict__ lane_bytes, const uint64_t* __restrict__ out_off,
                      uint8_t* __restrict__ out, const uint64_t* __restrict__ out_base, uint32_t n_lanes) {
-    const uint32_t lane = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (lane >= n_lanes) return;
-    const uint32_t t = threadIdx.x & 63u;
-    const uint8_t* src = pool + pool_off[lane];
-    uint8_t* dst = out + out_base[0] + out_off[lane];
-    const uint64_t n = lane_bytes[lane];
-    const uint64_t n16 = n >> 4;
-    for (uint64_t c = t; c < n16; c += 64) {
-        const uint4 v = *reinterpret_cast<const uint4*>(src + c * 16);
-        __builtin_memcpy(dst + c * 16, &v, 16);
+    __shared__ uint32_t tile_lds[CP_ROWS * 65];
+    __shared__ uint32_t s_max;
+    const uint32_t tile = blockIdx.x, t = threadIdx.x;
+    const uint32_t lane0 = tile * 64u;
+    if (t == 0) s_max = 0;
+    __syncthreads();
+    if (t < 64 && lane0 + t < n_lanes) atomicMax(&s_max, (uint32_t)lane_bytes[lane0 + t]);
+    __syncthreads();
+    const uint32_t max_bytes = s_max;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(pool + pool_off[tile]);
+    const uint64_t base = out_base[0];
+    for (uint32_t k0 = 0; k0 * 4u < max_bytes; k0 += CP_ROWS) {
+        // load CP_ROWS rows x 64 lanes (2048 words) coalesced
+#pragma unroll
+        for (uint32_t i = 0; i < (CP_ROWS * 64) / 256; i++) {
+            const uint32_t idx = t + i * 256u, row = idx >> 6, l = idx & 63u;
+            uint32_t v = 0;
+            if ((k0 + row) * 4u < max_bytes) v = src[(size_t)(k0 + row) * 64u + l];
+            tile_lds[row * 65u + l] = v;
+        }
+        __syncthreads();
+        // thread -> (lane, 16-byte piece): 8 consecutive threads cover one lane's 128 bytes
+#pragma unroll
+        for (uint32_t pass = 0; pass < 2; pass++) {
+            const uint32_t l = pass * 32u + (t >> 3), j = t & 7u;
+            const uint32_t lane = lane0 + l;
+            if (lane < n_lanes) {
+                const uint32_t nb = (uint32_t)lane_bytes[lane];
+                const uint32_t b0 = k0 * 4u + j * 16u;          // first byte of this piece in the lane's stream
+                if (b0 < nb) {
+                    uint32_t v[4];
+#pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) v[i] = tile_lds[(j * 4u + i) * 65u + l];
+                    uint8_t* dst = out + base + out_off[lane] + b0;
+                    if (b0 + 16u <= nb) {
+                        __builtin_memcpy(dst, v, 16);
+                    } else {
+                        for (uint32_t b = 0; b < nb - b0; b++) dst[b] = (uint8_t)(v[b >> 2] >> ((b & 3u) * 8u));
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
-    const uint64_t tail = n16 << 4;
-    if (tail + t < n) dst[tail + t] = src[tail + t];
 }
 
 // ---------------------------------------------------------------------------------------------
