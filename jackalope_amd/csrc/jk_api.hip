@@ -111,6 +111,10 @@ static void upload_genome(jk_session& s, const jk_ref_genome& g) {
     JK_HIP(hipMemset(s.d_seq.p, 'N', total));
     for (uint64_t i = 0; i < g.n_chroms; i++)
         if (len[i]) JK_HIP(hipMemcpy(s.d_seq.as<uint8_t>() + off[i], g.chrom_seqs[i], len[i], hipMemcpyHostToDevice));
+    // T,C,A,G -> 0..3, everything else -> 4 (what nt_map / cmp_map of the reference distinguish)
+    hipLaunchKernelGGL(encode_bases_kernel, dim3(2048), dim3(256), 0, 0, s.d_seq.as<uint8_t>(), total);
+    JK_HIP(hipGetLastError());
+    JK_HIP(hipDeviceSynchronize());
     std::vector<uint8_t> blob;
     std::vector<uint32_t> hoff(g.n_chroms + 1);
     for (uint64_t i = 0; i < g.n_chroms; i++) {
@@ -256,7 +260,7 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
     s.d_evw.alloc((size_t)s.n_ends * 4 * ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
     s.d_err.alloc(4);
 
-    s.lds_bytes = s.tables.thresh.size() * 8 + 256 * 8 + s.tables.info.size() * 4 + align_up(s.tables.quals.size() * 2, 16);
+    s.lds_bytes = (s.tables.thresh.size() + (s.tables.thresh.size() & 1)) * 8 + 256 * 8 + s.tables.info.size() * 4 + align_up(s.tables.quals.size() * 2, 16);
     s.lds_tables = s.lds_bytes <= 150 * 1024;
 
     IlluminaKernelParams& P = s.kp;
@@ -292,7 +296,10 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
     P.pool_size = a.read_pool_size;
     P.bc_len = (uint32_t)barcode.size();
     std::memset(P.barcode, 0, sizeof(P.barcode));
-    std::memcpy(P.barcode, barcode.data(), barcode.size());
+    for (size_t k = 0; k < barcode.size(); k++) {
+        const char c = barcode[k];
+        P.barcode[k] = c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : 4;
+    }
     P.info = s.d_info.as<uint32_t>(); P.thresh = s.d_thresh.as<uint64_t>();
     P.quals = s.d_quals.as<uint16_t>(); P.mm_thresh = s.d_mm.as<uint64_t>();
     P.n_info = (uint32_t)s.tables.info.size(); P.n_entries = (uint32_t)s.tables.thresh.size();

@@ -144,7 +144,7 @@ inline Threshold threshold_le(double c) { return prefix_end([c](uint64_t x) { re
 // ---- Illumina error-model tables, flattened for the kernel ------------------------------------
 struct IlluminaTables {
     uint32_t read_length = 0, n_ends = 0;
-    std::vector<uint32_t> info;     // [end][nt][pos] : first entry (24 bits) | n entries (8 bits)
+    std::vector<uint32_t> info;     // [end][pos][nt] : first entry (24 bits) | n entries (8 bits)
     std::vector<uint64_t> thresh;   // per entry: draw x2 picks the entry itself iff x2 < thresh
     std::vector<uint16_t> quals;    // per entry: quality if picked | quality of its alias << 8
     std::vector<uint64_t> mm_thresh;  // [256] : mismatch iff x3 < mm_thresh[q]  (qual_prob_map, hts_illumina.h:182-187)
@@ -152,6 +152,8 @@ struct IlluminaTables {
 
 inline void add_profile(IlluminaTables& T, const jk_illumina_profile& pr) {
     const uint32_t L = pr.read_length;
+    const size_t info0 = T.info.size();
+    T.info.resize(info0 + (size_t)4 * L);
     if (!pr.n_quals || !pr.probs || !pr.quals) throw Error(JK_ERR_ARG, "profile arrays must not be NULL");
     uint64_t off = 0;
     for (uint32_t nt = 0; nt < 4; nt++) {
@@ -162,7 +164,7 @@ inline void add_profile(IlluminaTables& T, const jk_illumina_profile& pr) {
             AliasTable at = alias_build(p);
             const uint64_t first = T.thresh.size();
             if (first + k >= (1u << 24)) throw Error(JK_ERR_UNSUPPORTED, "quality profile too large");
-            T.info.push_back(static_cast<uint32_t>(first) | (k << 24));
+            T.info[info0 + (size_t)pos * 4 + nt] = static_cast<uint32_t>(first) | (k << 24);
             for (uint32_t i = 0; i < k; i++) {
                 Threshold th = threshold_lt(at.prob[i]);
                 const uint8_t q_self = pr.quals[off + i];

@@ -39,7 +39,8 @@ enum : uint32_t {
 };
 
 struct GenomeDev {
-    const uint8_t* seq;          // all chromosomes, 1 byte per base as given, 64-B padded
+    const uint8_t* seq;          // all chromosomes, 1 byte per base, 64-B padded, ENCODED on upload:
+                                 // T=0 C=1 A=2 G=3 (jlp::bases order), anything else = 4
     const uint64_t* chrom_off;   // [n_chroms] byte offset of chromosome in seq
     const uint64_t* chrom_len;   // [n_chroms]
     const uint8_t* hdr_blob;     // "@<genome>-<chrom>-" per chromosome
@@ -70,50 +71,42 @@ struct IlluminaKernelParams {
     uint32_t never_match[2], never_del[2];
     uint64_t th_dup; uint32_t dup_all;
     uint64_t pool_size;
-    uint32_t bc_len; uint8_t barcode[JK_MAX_BARCODE];
+    uint32_t bc_len; uint8_t barcode[JK_MAX_BARCODE];      // encoded like the genome
     // tables (global copies; staged to LDS when LDS_TAB)
+    // info: [end][pos][nt] -> first entry (24 bits) | n entries (8 bits), 16 bytes per (end,pos)
     const uint32_t* info; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm_thresh;
     uint32_t n_info, n_entries;
 };
 
 // ---------------------------------------------------------------------------------------------
 // Byte appender into a lane's pool (one column of its tile).  Bytes are gathered into a 32-bit word
-// and stored when the word is complete; the first (partial) word of a stream that starts mid-word is
-// written byte by byte because its low bytes belong to whoever wrote before.
+// and stored when the word is complete.  A stream that starts mid-word stores that first word with
+// zeros in the bytes below its start: those bytes belong to the stream that ends there, which
+// writes them LATER in program order and byte by byte (os_flush), so nothing is lost.
 // ---------------------------------------------------------------------------------------------
 struct OutStream {
     uint8_t* wp;       // address of the current word (this lane's column of the tile)
     uint32_t pos;      // byte offset in the lane's stream
     uint32_t w;        // bytes gathered for the current word
-    uint32_t head;     // 1 while the current word started mid-word
 };
 
 constexpr uint32_t TILE_ROW = 64 * 4;      // bytes between consecutive words of one lane
 
 __device__ __forceinline__ void os_begin(OutStream& s, uint8_t* lane_base, uint32_t pos) {
     s.wp = lane_base + (size_t)(pos >> 2) * TILE_ROW;
-    s.pos = pos; s.w = 0; s.head = (pos & 3u) ? 1u : 0u;
+    s.pos = pos; s.w = 0;
 }
 __device__ __forceinline__ void os_put(OutStream& s, uint32_t byte) {
     const uint32_t k = s.pos & 3u;
-    if (s.head) {
-        s.wp[k] = (uint8_t)byte;
-        if (k == 3u) s.head = 0;
-    } else {
-        s.w |= byte << (8u * k);
-        if (k == 3u) { *reinterpret_cast<uint32_t*>(s.wp) = s.w; s.w = 0; }
-    }
-    if (k == 3u) s.wp += TILE_ROW;
+    s.w |= byte << (8u * k);
     s.pos++;
+    if (k == 3u) { *reinterpret_cast<uint32_t*>(s.wp) = s.w; s.w = 0; s.wp += TILE_ROW; }
 }
-// write out whatever is pending in the current word (as bytes); the stream can be abandoned after
+// write the pending bytes of the current word one by one; the stream is abandoned afterwards
 __device__ __forceinline__ void os_flush(OutStream& s) {
     const uint32_t k = s.pos & 3u;
-    if (!s.head) {
-        for (uint32_t j = 0; j < k; j++) s.wp[j] = (uint8_t)(s.w >> (8u * j));
-    }
+    for (uint32_t j = 0; j < k; j++) s.wp[j] = (uint8_t)(s.w >> (8u * j));
     s.w = 0;
-    s.head = k ? 1u : 0u;     // if anything more is appended it continues this (already written) word
 }
 
 struct LaneRng {
@@ -121,18 +114,26 @@ struct LaneRng {
     __device__ __forceinline__ uint64_t operator()() { return jk_pcg_next(e); }
 };
 
-__device__ __forceinline__ uint32_t nt_index(uint32_t c) {
-    // T0 C1 A2 G3, anything else 4 (sequencer::nt_map, src/hts.h:36-44)
-    return c == 'T' ? 0u : c == 'C' ? 1u : c == 'A' ? 2u : c == 'G' ? 3u : 4u;
-}
-__device__ __forceinline__ uint32_t cmp_base(uint32_t c) {
-    // str_manip::cmp_map (src/str_manip.h:58-72): T<->A, C<->G, N->N, everything else -> 0
-    return c == 'T' ? 'A' : c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'N' ? 'N' : 0u;
+// (uint64)(runif_01 * n) for n < 2^32: same value as jk_runif_index, two 32x32 multiply-adds.
+__device__ __forceinline__ uint32_t runif_index32(uint64_t x, uint32_t n) {
+    const uint64_t t0 = (uint64_t)(uint32_t)x * n + n;                  // < 2^64
+    const uint64_t t1 = (uint64_t)(uint32_t)(x >> 32) * n + (t0 >> 32);  // (x+1)*n = t1 * 2^32 + lo32(t0)
+    uint32_t hi = (uint32_t)(t1 >> 32);
+    // x87 rounding of the product can only carry into `hi` when the low 64 bits are within 2^31 of 2^64
+    if ((uint32_t)t1 == 0xffffffffu && hi != 0) {
+        const uint64_t lo = (t1 << 32) | (uint32_t)t0;
+        const uint64_t half = 1ULL << (31 - __builtin_clz(hi));
+        if (lo + half < lo) hi++;
+    }
+    return hi;
 }
 
-// tables either in LDS (Tab::lds = true) or global
+// code (T0 C1 A2 G3) -> ASCII
+__device__ __forceinline__ uint32_t base_char(uint32_t code) { return (0x47414354u >> (8u * code)) & 0xffu; }
+
+// tables either in LDS or global
 struct TabPtrs {
-    const uint32_t* info; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm;
+    const uint4* info4; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm;
 };
 
 // NE = number of read ends (1 single-end, 2 paired); BLOCK = workgroup size (1024 -> 4 waves/SIMD and a
@@ -145,15 +146,15 @@ illumina_ref_kernel(IlluminaKernelParams P) {
     if (LDS_TAB) {
         uint64_t* s_thresh = reinterpret_cast<uint64_t*>(smem);
         uint64_t* s_mm = s_thresh + P.n_entries;
-        uint32_t* s_info = reinterpret_cast<uint32_t*>(s_mm + 256);
+        uint32_t* s_info = reinterpret_cast<uint32_t*>(s_mm + 256 + (P.n_entries & 1u));   // keep 16-byte alignment
         uint16_t* s_quals = reinterpret_cast<uint16_t*>(s_info + P.n_info);
         for (uint32_t i = threadIdx.x; i < P.n_entries; i += blockDim.x) { s_thresh[i] = P.thresh[i]; s_quals[i] = P.quals[i]; }
         for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_mm[i] = P.mm_thresh[i];
         for (uint32_t i = threadIdx.x; i < P.n_info; i += blockDim.x) s_info[i] = P.info[i];
         __syncthreads();
-        T.info = s_info; T.thresh = s_thresh; T.quals = s_quals; T.mm = s_mm;
+        T.info4 = reinterpret_cast<const uint4*>(s_info); T.thresh = s_thresh; T.quals = s_quals; T.mm = s_mm;
     } else {
-        T.info = P.info; T.thresh = P.thresh; T.quals = P.quals; T.mm = P.mm_thresh;
+        T.info4 = reinterpret_cast<const uint4*>(P.info); T.thresh = P.thresh; T.quals = P.quals; T.mm = P.mm_thresh;
     }
 
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,7 +186,10 @@ illumina_ref_kernel(IlluminaKernelParams P) {
     uint32_t err = 0;
     const uint32_t W = P.ev_words;
     const size_t ev_stride = (size_t)P.n_lanes;
-    // plane p of end r, word w  ->  evw[((r*4 + p) * W + w) * n_lanes + lane]; p: 0 ins, 1 del, 2/3 inserted base bits
+    // Indel events of the current read ends live in per-lane bitmaps in HBM (they are rare: ~0.03 per
+    // read): plane p of end r, word w -> evw[((r*4 + p) * W + w) * n_lanes + lane]; p: 0 insertions,
+    // 1 deletions, 2/3 the two bits of each inserted base.  `evalid` says which words were written
+    // for this read (bits 0-15 insertion words, 16-31 deletion words).
     auto evaddr = [&](uint32_t r, uint32_t p, uint32_t w) -> uint64_t* {
         return P.evw + ((size_t)((r * 4 + p) * W + w)) * ev_stride + lane;
     };
@@ -204,45 +208,41 @@ illumina_ref_kernel(IlluminaKernelParams P) {
             if (frag_len >= chrom_len) { frag_len = chrom_len; frag_start = 0; }
             else frag_start = jk_frag_start(rng(), chrom_len - frag_len + 1);
         }
-        // ---- sample_indels + adjust_chrom_spaces (hts_illumina.cpp:117-184)
-        uint32_t space[2], out_len[2], evmask[2];   // evmask: bit w set = word w of (ins|del) non-zero
+        // ---- sample_indels + adjust_chrom_spaces (hts_illumina.cpp:117-184): one draw per fragment
+        // position; anything but a match is rare and is recorded in the HBM bitmaps
+        uint32_t space[2], out_len[2], evalid[2];
+        const uint32_t fl32 = frag_len > 0xffffffffULL ? 0xffffffffu : (uint32_t)frag_len;
 #pragma unroll
         for (uint32_t r = 0; r < NE; r++) {
-            uint64_t frag_pos = 0; uint32_t len_now = 0, n_ins = 0, n_del = 0, em = 0;
-            uint64_t iw = 0, dw = 0;
+            uint32_t frag_pos = 0, len_now = 0, n_ins = 0, n_del = 0, ev = 0;
             const uint64_t thm = P.th_match[r], thd = P.th_del[r];
             const bool nm = P.never_match[r], nd = P.never_del[r];
-            while (len_now < L && frag_pos < frag_len) {
-                if (frag_pos >= (uint64_t)W * 64) { err |= JK_KERR_TOO_MANY_DELETIONS; break; }
+            while (len_now < L && frag_pos < fl32) {
                 const uint64_t x = rng();
                 if (!nm && x >= thm) {
                     len_now++;
-                } else if (!nd && x >= thd) {
-                    dw |= 1ULL << (frag_pos & 63); n_del++;
                 } else {
-                    if (len_now == L - 1) len_now++;
-                    else { iw |= 1ULL << (frag_pos & 63); n_ins++; len_now += 2; }
-                }
-                frag_pos++;
-                if ((frag_pos & 63) == 0) {
-                    const uint32_t w = (uint32_t)(frag_pos >> 6) - 1;
-                    if (iw | dw) {
-                        if (w < W) { *evaddr(r, 0, w) = iw; *evaddr(r, 1, w) = dw; em |= 1u << w; }
-                        else err |= JK_KERR_TOO_MANY_DELETIONS;
-                        iw = 0; dw = 0;
+                    const bool is_del = !nd && x >= thd;
+                    if (!is_del && len_now == L - 1) {
+                        len_now++;                       // insertion after the last base: counted, not recorded
+                    } else {
+                        const uint32_t w = frag_pos >> 6;
+                        if (w >= W) { err |= JK_KERR_TOO_MANY_DELETIONS; break; }
+                        const uint32_t vb = (is_del ? 16u : 0u) + w;
+                        uint64_t* a = evaddr(r, is_del ? 1u : 0u, w);
+                        const uint64_t old = ((ev >> vb) & 1u) ? *a : 0ULL;
+                        *a = old | (1ULL << (frag_pos & 63u));
+                        ev |= 1u << vb;
+                        if (is_del) n_del++; else { n_ins++; len_now += 2; }
                     }
                 }
-            }
-            if (iw | dw) {
-                const uint32_t w = (uint32_t)(frag_pos >> 6);
-                if (w < W) { *evaddr(r, 0, w) = iw; *evaddr(r, 1, w) = dw; em |= 1u << w; }
-                else err |= JK_KERR_TOO_MANY_DELETIONS;
+                frag_pos++;
             }
             uint64_t sp = (uint64_t)L + n_del - n_ins;
             if (sp > frag_len) sp = frag_len;
             space[r] = (uint32_t)sp;
             out_len[r] = (uint32_t)sp - n_del + n_ins;
-            evmask[r] = em;
+            evalid[r] = ev;
         }
         if (err) break;
 
@@ -250,18 +250,18 @@ illumina_ref_kernel(IlluminaKernelParams P) {
         bool reverse = jk_runif_lt_half(rng());
 #pragma unroll
         for (uint32_t i = 0; i < NE; i++) {
-            const uint32_t sp = space[i], n_out = out_len[i], em = evmask[i];
+            const uint32_t sp = space[i], n_out = out_len[i], ev = evalid[i];
+            const uint32_t ev_any = (ev | (ev >> 16)) & 0xffffu;      // words with any event
             const uint64_t cspace = (uint64_t)sp - bc;
             uint64_t start;
             if ((!P.matepair && !reverse) || (P.matepair && reverse)) start = frag_start;
             else start = frag_start + frag_len - cspace;
 
             // inserted bases are drawn first, right to left (hts_illumina.h:213-225)
-            if (em) {
+            if (ev & 0xffffu) {
                 for (int w = (int)W - 1; w >= 0; w--) {
-                    if (!((em >> w) & 1u)) continue;
-                    uint64_t iw = *evaddr(i, 0, w), b0 = 0, b1 = 0;
-                    uint64_t rest = iw;
+                    if (!((ev >> w) & 1u)) continue;
+                    uint64_t rest = *evaddr(i, 0, w), b0 = 0, b1 = 0;
                     while (rest) {
                         const int bit = 63 - jk_clz64(rest);
                         rest &= ~(1ULL << bit);
@@ -299,73 +299,108 @@ illumina_ref_kernel(IlluminaKernelParams P) {
             os_begin(oq, i == 0 ? base0 : base1, o.pos + n_out);
             os_put(oq, '\n'); os_put(oq, '+'); os_put(oq, '\n');
 
-            // ---- bases + qualities (fill_read / rev_comp / fill_read_qual)
-            const uint64_t chrom_base = P.g.chrom_off[ci];
-            uint64_t gbuf = 0;
-            uint32_t gchunk = ~(uint32_t)((chrom_base + (reverse ? (start + sp - 1 - bc) : start)) >> 3);   // != first chunk
-            // source position pp of the (pre-indel) read: pp < bc barcode; else forward chrom[start + pp - bc],
-            // reverse: complement of chrom[start + sp - 1 - pp]
-            uint64_t gpos = reverse ? (start + sp - 1 - bc) : start;
+            // ---- bases + qualities (fill_read / rev_comp / fill_read_qual).
+            // Source position pp of the pre-indel read: pp < bc -> barcode; else forward
+            // chrom[start + pp - bc], reverse: complement of chrom[start + sp - 1 - pp].  The reference
+            // bytes are consumed low byte first from an 8-byte register chunk; for the reverse strand
+            // the chunk is byte-swapped and complemented when it is loaded.
+            const uint8_t* const gseq = P.g.seq;
+            uint64_t gaddr;          // byte address (index into gseq) of the NEXT chunk to load
+            uint64_t gbuf; uint32_t gcnt;
+            {
+                const uint64_t a0 = P.g.chrom_off[ci] + (reverse ? (start + sp - 1 - bc) : start);
+                const uint64_t ch = a0 & ~7ULL;
+                uint64_t v = *reinterpret_cast<const uint64_t*>(gseq + ch);
+                const uint32_t k = (uint32_t)a0 & 7u;
+                if (reverse) {
+                    v = __builtin_bswap64(v);
+                    v ^= ((~v) >> 1) & 0x0202020202020202ULL;       // codes 0..3: ^2 (T<->A, C<->G); 4 stays
+                    gbuf = v >> (8u * (7u - k)); gcnt = k + 1; gaddr = ch - 8;
+                } else {
+                    gbuf = v >> (8u * k); gcnt = 8u - k; gaddr = ch + 8;
+                }
+            }
+            auto src_next = [&]() -> uint32_t {
+                const uint32_t c = (uint32_t)gbuf & 0xffu;
+                gbuf >>= 8;
+                if (--gcnt == 0) {
+                    uint64_t v = *reinterpret_cast<const uint64_t*>(gseq + gaddr);
+                    if (reverse) {
+                        v = __builtin_bswap64(v);
+                        v ^= ((~v) >> 1) & 0x0202020202020202ULL;
+                        gaddr -= 8;
+                    } else gaddr += 8;
+                    gbuf = v; gcnt = 8;
+                }
+                return c;
+            };
+            // first position of (ins|del) at or after pp, or "none"
+            auto next_event = [&](uint32_t pp) -> uint32_t {
+                for (uint32_t w = pp >> 6; w < W; w++) {
+                    if (!((ev_any >> w) & 1u)) continue;
+                    uint64_t m = (((ev >> w) & 1u) ? *evaddr(i, 0, w) : 0ULL) | (((ev >> (16 + w)) & 1u) ? *evaddr(i, 1, w) : 0ULL);
+                    if (w == (pp >> 6)) m &= ~0ULL << (pp & 63u);
+                    if (m) return w * 64u + (uint32_t)__builtin_ctzll(m);
+                }
+                return 0xffffffffu;
+            };
+
             uint32_t pp = 0;
-            uint64_t iw = 0, dw = 0, b0w = 0, b1w = 0;
-            if (em & 1u) { iw = *evaddr(i, 0, 0); dw = *evaddr(i, 1, 0); b0w = *evaddr(i, 2, 0); b1w = *evaddr(i, 3, 0); }
+            // `nes`: the next source position that needs the slow path (barcode, deletion, insertion);
+            // 0 forces it for the next base (pending inserted base).
+            uint32_t nes = bc ? 0u : (ev_any ? next_event(0) : 0xffffffffu);
             bool pending = false; uint32_t pend_base = 0;
-            const uint32_t tab_base = i * 4u * L;
+            const uint32_t info_base = i * L;
             for (uint32_t op = 0; op < n_out; op++) {
+                const uint4 inf4 = T.info4[info_base + op];
                 uint32_t c;
-                if (pending) {
-                    c = (pend_base == 0 ? 'T' : pend_base == 1 ? 'C' : pend_base == 2 ? 'A' : 'G');
-                    pending = false;
-                } else {
-                    for (;;) {
-                        const uint32_t bit = pp & 63u;
-                        const bool deleted = em && ((dw >> bit) & 1ULL);
-                        if (!deleted) {
-                            if (pp < bc) c = P.barcode[pp];
-                            else {
-                                const uint64_t a = chrom_base + gpos;
-                                const uint32_t ch = (uint32_t)(a >> 3);
-                                if (ch != gchunk) { gbuf = *reinterpret_cast<const uint64_t*>(P.g.seq + ((a >> 3) << 3)); gchunk = ch; }
-                                c = (uint32_t)(gbuf >> (((uint32_t)a & 7u) * 8u)) & 0xffu;
-                                if (reverse) c = cmp_base(c);
-                            }
-                            if (em && ((iw >> bit) & 1ULL)) {
-                                pending = true;
-                                pend_base = (uint32_t)((b0w >> bit) & 1ULL) | ((uint32_t)((b1w >> bit) & 1ULL) << 1);
-                            }
+                if (pp < nes) {                 // fast path: next reference base
+                    c = src_next();
+                    pp++;
+                } else {                        // slow path (rare)
+                    if (pending) {
+                        c = pend_base; pending = false;
+                    } else {
+                        for (;;) {
+                            const uint32_t w = pp >> 6, bit = pp & 63u;
+                            const bool deleted = w < W && ((ev >> (16 + w)) & 1u) && ((*evaddr(i, 1, w) >> bit) & 1ULL);
+                            if (!deleted) break;
+                            if (pp >= bc) (void)src_next();
+                            pp++;
                         }
-                        if (pp >= bc) gpos += reverse ? (uint64_t)-1 : 1;
+                        c = (pp < bc) ? (uint32_t)P.barcode[pp] : src_next();
+                        const uint32_t w = pp >> 6, bit = pp & 63u;
+                        if (w < W && ((ev >> w) & 1u) && ((*evaddr(i, 0, w) >> bit) & 1ULL)) {
+                            pending = true;
+                            pend_base = (uint32_t)((*evaddr(i, 2, w) >> bit) & 1ULL) | ((uint32_t)((*evaddr(i, 3, w) >> bit) & 1ULL) << 1);
+                        }
                         pp++;
-                        if (em && (pp & 63u) == 0) {
-                            const uint32_t w = pp >> 6;
-                            if (w < W && ((em >> w) & 1u)) { iw = *evaddr(i, 0, w); dw = *evaddr(i, 1, w); b0w = *evaddr(i, 2, w); b1w = *evaddr(i, 3, w); }
-                            else { iw = dw = b0w = b1w = 0; }
-                        }
-                        if (!deleted) break;
                     }
+                    nes = pending ? 0u : (pp < bc ? pp : (ev_any ? next_event(pp) : 0xffffffffu));
                 }
-                const uint32_t nt = nt_index(c);
-                uint32_t q;
-                if (nt > 3) {
-                    q = jk_n_qual(rng());
-                    c = 'N';
-                } else {
-                    const uint32_t inf = T.info[tab_base + nt * L + op];
-                    const uint32_t first = inf & 0xffffffu, n = inf >> 24;
-                    const uint32_t e = first + (uint32_t)jk_runif_index(rng(), n);
-                    const uint64_t x2 = rng();
+                uint32_t q, ch;
+                if (c < 4u) {
+                    const uint32_t inf = c == 0 ? inf4.x : c == 1 ? inf4.y : c == 2 ? inf4.z : inf4.w;
+                    const uint64_t x1 = rng();
+                    const uint32_t e = (inf & 0xffffffu) + runif_index32(x1, inf >> 24);
+                    const uint64_t th = T.thresh[e];
                     const uint32_t qq = T.quals[e];
-                    const uint32_t k = (x2 < T.thresh[e]) ? (qq & 0xffu) : (qq >> 8);
-                    q = (k + 33u) & 0xffu;
+                    const uint64_t x2 = rng();
                     const uint64_t x3 = rng();
-                    if (x3 < T.mm[k]) {
-                        const uint32_t m = (uint32_t)jk_runif_index(rng(), 3);
-                        // mm_nucleos = {"CAG","TAG","TCG","TCA"} (src/hts.h:46)
-                        const uint32_t packed = nt == 0 ? 0x474143u : nt == 1 ? 0x474154u : nt == 2 ? 0x474354u : 0x414354u;
-                        c = (m < 3) ? ((packed >> (8u * m)) & 0xffu) : 0u;
+                    const uint32_t k = (x2 < th) ? (qq & 0xffu) : (qq >> 8);
+                    const uint64_t mmth = T.mm[k];
+                    q = (k + 33u) & 0xffu;
+                    ch = base_char(c);
+                    if (x3 < mmth) {
+                        // mm_nucleos = {"CAG","TAG","TCG","TCA"} (src/hts.h:46): the m-th base that is not c
+                        const uint32_t m = runif_index32(rng(), 3);
+                        ch = (m < 3u) ? base_char(m + (m >= c ? 1u : 0u)) : 0u;
                     }
+                } else {
+                    q = jk_n_qual(rng());
+                    ch = 'N';
                 }
-                os_put(o, c);
+                os_put(o, ch);
                 os_put(oq, q);
             }
             os_put(oq, '\n');
@@ -399,6 +434,16 @@ illumina_ref_kernel(IlluminaKernelParams P) {
     }
     P.lane_made[lane] = made;
     if (err) atomicOr(P.err, err);
+}
+
+// ASCII -> code, in place (run once per uploaded buffer)
+__global__ void encode_bases_kernel(uint8_t* seq, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t k = i; k < n; k += stride) {
+        const uint8_t c = seq[k];
+        seq[k] = c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : 4;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
