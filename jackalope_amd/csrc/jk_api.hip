@@ -73,7 +73,10 @@ struct jk_session {
     DevBuf d_info, d_thresh, d_quals, d_mm;
     bool lds_tables = false;
     size_t lds_bytes = 0;
-    int block = 1024;          // generator workgroup size (JK_BLOCK=512 selects the 256-VGPR variant)
+    bool hap = false;
+    uint32_t ev_words = 0;
+    uint64_t nuc_base = 0;     // offset of the haplotypes' nucleotide blob inside d_seq
+    DevBuf d_cell_off, d_new_pos, d_ref_shift, d_nuc_len, d_nuc_off, d_cell_size, d_bc_blob, d_bc_len;
     // lanes of this shard
     uint64_t n_lanes_total = 0, lane_begin = 0, lane_end = 0, n_shard = 0;
     std::vector<uint64_t> pool_off_host;          // per batch-relative offsets, concatenated per batch (n+1 each)
@@ -100,38 +103,35 @@ struct jk_session {
 
 namespace jk {
 
-static void upload_genome(jk_session& s, const jk_ref_genome& g) {
+// Chromosomes (+ optionally the haplotypes' nucleotide blob) into one encoded device buffer.
+static void upload_genome(jk_session& s, const jk_ref_genome& g, const char* blob_bytes, uint64_t blob_len) {
     if (g.n_chroms == 0) throw Error(JK_ERR_ARG, "reference genome has no chromosomes");
     if (g.n_chroms > 0xffffffffULL) throw Error(JK_ERR_UNSUPPORTED, "too many chromosomes");
-    const std::string gname = g.name ? g.name : "REF";
     std::vector<uint64_t> off(g.n_chroms), len(g.n_chroms);
     uint64_t total = 64;
     for (uint64_t i = 0; i < g.n_chroms; i++) { off[i] = total; len[i] = g.chrom_lens[i]; total = align_up(total + len[i], 64) + 64; }
+    s.nuc_base = total;
+    total = align_up(total + blob_len, 64) + 64;
     s.d_seq.alloc(total);
     JK_HIP(hipMemset(s.d_seq.p, 'N', total));
+    if (blob_len) JK_HIP(hipMemcpy(s.d_seq.as<uint8_t>() + s.nuc_base, blob_bytes, blob_len, hipMemcpyHostToDevice));
     for (uint64_t i = 0; i < g.n_chroms; i++)
         if (len[i]) JK_HIP(hipMemcpy(s.d_seq.as<uint8_t>() + off[i], g.chrom_seqs[i], len[i], hipMemcpyHostToDevice));
     // T,C,A,G -> 0..3, everything else -> 4 (what nt_map / cmp_map of the reference distinguish)
     hipLaunchKernelGGL(encode_bases_kernel, dim3(2048), dim3(256), 0, 0, s.d_seq.as<uint8_t>(), total);
     JK_HIP(hipGetLastError());
     JK_HIP(hipDeviceSynchronize());
-    std::vector<uint8_t> blob;
-    std::vector<uint32_t> hoff(g.n_chroms + 1);
-    for (uint64_t i = 0; i < g.n_chroms; i++) {
-        hoff[i] = (uint32_t)blob.size();
-        std::string h = "@" + gname + "-" + (g.chrom_names ? g.chrom_names[i] : "") + "-";
-        blob.insert(blob.end(), h.begin(), h.end());
-    }
-    hoff[g.n_chroms] = (uint32_t)blob.size();
     s.d_chrom_off.upload(off);
     s.d_chrom_len.upload(len);
-    s.d_hdr_blob.upload(blob);
-    s.d_hdr_off.upload(hoff);
     s.n_chroms = (uint32_t)g.n_chroms;
 }
 
-// Everything the reference does on the calling thread before the parallel region, plus device set-up.
-static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_illumina_args& a) {
+static inline uint8_t encode_base(char c) { return c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : 4; }
+
+// ---- pieces shared by the reference-genome and haplotype entry points --------------------------
+
+// Argument checks + error-model tables + every per-run constant of the kernel.
+static void setup_model(jk_session& s, const jk_illumina_args& a) {
     if (a.compress > 0) throw Error(JK_ERR_UNSUPPORTED, "compressed FASTQ output is not implemented on the GPU path (write uncompressed, then gzip/bgzip)");
     if (a.frag_len_shape < 1.0) throw Error(JK_ERR_UNSUPPORTED, "frag_len_shape < 1 (fragment sd > mean) is not implemented on the GPU path");
     if (!(a.frag_len_scale > 0)) throw Error(JK_ERR_ARG, "frag_len_scale must be > 0");
@@ -145,13 +145,156 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
 
     s.tables = build_illumina_tables(a);
     const uint32_t L = s.tables.read_length;
-    const std::string barcode = (a.barcodes && a.n_barcodes > 0 && a.barcodes[0]) ? a.barcodes[0] : "";
-    if (barcode.size() > (size_t)JK_MAX_BARCODE) throw Error(JK_ERR_UNSUPPORTED, "barcodes longer than 32 bases are not implemented on the GPU path");
-    if (barcode.size() >= L) throw Error(JK_ERR_ARG, "barcode must be shorter than the read length");
-    const uint32_t ev_words = (2 * L + 63) / 64 + 1;
-    if (ev_words > (uint32_t)JK_MAX_EVW) throw Error(JK_ERR_UNSUPPORTED, "read lengths above 480 are not implemented on the GPU path");
+    s.ev_words = (2 * L + 63) / 64 + 1;
+    if (s.ev_words > (uint32_t)JK_MAX_EVW) throw Error(JK_ERR_UNSUPPORTED, "read lengths above 480 are not implemented on the GPU path");
 
-    upload_genome(s, g);
+    IlluminaKernelParams& P = s.kp;
+    P.read_len = L; P.n_ends = s.n_ends; P.paired = s.paired; P.matepair = (s.paired && a.matepair) ? 1 : 0;
+    P.ev_words = s.ev_words;
+    P.frag_min = a.frag_len_min; P.frag_max = a.frag_len_max;
+    {   // gamma_distribution<double>::param_type::_M_initialize (random.tcc:2330-2346), alpha >= 1
+        const double a1 = a.frag_len_shape - 1.0 / 3.0;
+        P.gp.a1 = a1;
+        P.gp.a2 = 1.0 / std::sqrt(9.0 * a1);
+        P.gp.beta = a.frag_len_scale;
+    }
+    const double insp[2] = {a.ins_prob1, a.ins_prob2}, delp[2] = {a.del_prob1, a.del_prob2};
+    for (uint32_t r = 0; r < 2; r++) {
+        // u > (ins + del) -> match ; else u > ins -> deletion ; else insertion (hts_illumina.cpp:133-144)
+        Threshold tm = threshold_le(insp[r] + delp[r]);
+        Threshold td = threshold_le(insp[r]);
+        P.th_match[r] = tm.th; P.never_match[r] = tm.all;
+        P.th_del[r] = td.th; P.never_del[r] = td.all;
+    }
+    {   // dup < prob_dup (src/hts.h:265-266)
+        Threshold t = threshold_lt(a.prob_dup);
+        P.th_dup = t.th; P.dup_all = t.all;
+    }
+    P.pool_size = a.read_pool_size;
+}
+
+static void check_barcode(const std::string& bc, uint32_t L) {
+    if (bc.size() > (size_t)JK_MAX_BARCODE) throw Error(JK_ERR_UNSUPPORTED, "barcodes longer than 32 bases are not implemented on the GPU path");
+    if (bc.size() >= L) throw Error(JK_ERR_ARG, "barcode must be shorter than the read length");
+}
+
+// Lanes of the run and of this process's shard; per-lane read quotas (src/hts.h:334-336).
+static std::vector<uint64_t> plan_lanes(jk_session& s, const jk_illumina_args& a, uint64_t n_reads) {
+    uint64_t T = a.n_threads ? a.n_threads : 1;
+    s.n_lanes_total = T;
+    s.lane_begin = a.lane_begin;
+    s.lane_end = a.lane_end ? a.lane_end : T;
+    if (s.lane_begin > s.lane_end || s.lane_end > T) throw Error(JK_ERR_ARG, "lane shard out of range");
+    s.n_shard = s.lane_end - s.lane_begin;
+    std::vector<uint64_t> per_lane = split_int(n_reads / s.n_ends, T);
+    for (uint64_t& v : per_lane) v *= s.n_ends;
+    if (per_lane[0] > 0xffffffffULL) throw Error(JK_ERR_UNSUPPORTED, "more than 2^32 reads per lane: raise n_threads");
+    return per_lane;
+}
+
+// mt_seeds (src/pcg.h:37-46): 8 words per lane for ALL lanes, in lane order; keep this shard's.
+static std::vector<uint32_t> take_lane_seeds(jk_session& s, SeedReader& seeds) {
+    std::vector<uint32_t> lane_seeds(s.n_shard * 8);
+    uint32_t w[8];
+    for (uint64_t t = 0; t < s.n_lanes_total; t++) {
+        seeds.take8(w);
+        if (t >= s.lane_begin && t < s.lane_end) std::memcpy(&lane_seeds[(t - s.lane_begin) * 8], w, sizeof(w));
+    }
+    return lane_seeds;
+}
+
+// Pools: tiles of 64 lanes (one wave), every lane of a tile gets the capacity of the tile's largest
+// quota of maximal records; a batch is a run of whole tiles.  Then all device buffers.
+static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const std::vector<uint64_t>& lane_reads,
+                                 uint64_t rec_max, const std::vector<uint32_t>& lane_seeds,
+                                 const std::vector<uint32_t>& quotas) {
+    const uint64_t max_batch = a.max_batch_bytes ? a.max_batch_bytes : (8ULL << 30);
+    const uint64_t max_batch_lanes = 1ULL << 22;
+    std::vector<uint64_t> pool_off;    // concatenation over batches of (n_tiles+1) relative offsets
+    uint64_t out_cap = 0, max_pool = 0;
+    uint32_t max_lanes = 0;
+    uint64_t l = 0;
+    while (l < s.n_shard) {
+        Batch b{l, 0, 0};
+        s.batch_pool_off_index.push_back(pool_off.size());
+        pool_off.push_back(0);
+        uint64_t used = 0;
+        while (l < s.n_shard && b.n_lanes < max_batch_lanes) {
+            const uint64_t tl = std::min<uint64_t>(64, s.n_shard - l);
+            uint64_t maxq = 0;
+            for (uint64_t k = 0; k < tl; k++) maxq = std::max(maxq, lane_reads[l + k] / s.n_ends);
+            const uint64_t cap = align_up(maxq * rec_max, 4) * 64;
+            if (b.n_lanes > 0 && used + cap > max_batch) break;
+            used += cap; pool_off.push_back(used); b.n_lanes += (uint32_t)tl; l += tl;
+        }
+        b.pool_bytes = used;
+        out_cap += used;
+        max_pool = std::max(max_pool, used);
+        max_lanes = std::max(max_lanes, b.n_lanes);
+        s.batches.push_back(b);
+    }
+    s.out_cap = out_cap;
+
+    s.d_seeds.upload(lane_seeds);
+    s.d_lane_reads.upload(lane_reads);
+    s.d_chrom_reads.upload(quotas);
+    s.d_pool_off.upload(pool_off);
+    s.d_info.upload(s.tables.info);
+    s.d_thresh.upload(s.tables.thresh);
+    s.d_quals.upload(s.tables.quals);
+    s.d_mm.upload(s.tables.mm_thresh);
+    for (uint32_t e = 0; e < s.n_ends; e++) {
+        s.d_pool[e].alloc(max_pool + 64);
+        s.d_out[e].alloc(out_cap + 64);
+        s.d_lane_bytes[e].alloc(s.n_shard * 8);
+        s.d_lane_off[e].alloc(s.n_shard * 8);
+        s.d_base[e].alloc((s.batches.size() + 1) * 8);
+    }
+    s.d_lane_made.alloc(s.n_shard * 8);
+    s.d_block_sums.alloc((max_lanes / SCAN_BLOCK + 2) * 8);
+    s.d_evw.alloc((size_t)s.n_ends * 4 * s.ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
+    s.d_err.alloc(4);
+
+    s.lds_bytes = (s.tables.thresh.size() + (s.tables.thresh.size() & 1)) * 8 + 256 * 8 + s.tables.info.size() * 4 + align_up(s.tables.quals.size() * 2, 16);
+    s.lds_tables = s.lds_bytes <= 150 * 1024;
+
+    IlluminaKernelParams& P = s.kp;
+    P.g.seq = s.d_seq.as<uint8_t>();
+    P.g.chrom_off = s.d_chrom_off.as<uint64_t>();
+    P.g.chrom_len = s.d_chrom_len.as<uint64_t>();
+    P.g.hdr_blob = s.d_hdr_blob.as<uint8_t>();
+    P.g.hdr_off = s.d_hdr_off.as<uint32_t>();
+    P.g.n_chroms = s.n_chroms;
+    P.evw = s.d_evw.as<uint64_t>();
+    P.err = s.d_err.as<uint32_t>();
+    P.info = s.d_info.as<uint32_t>(); P.thresh = s.d_thresh.as<uint64_t>();
+    P.quals = s.d_quals.as<uint16_t>(); P.mm_thresh = s.d_mm.as<uint64_t>();
+    P.n_info = (uint32_t)s.tables.info.size(); P.n_entries = (uint32_t)s.tables.thresh.size();
+
+    const size_t n_ev = 2 + 2 * s.batches.size() + 2;
+    s.events.resize(n_ev);
+    for (hipEvent_t& e : s.events) JK_HIP(hipEventCreate(&e));
+    if (s.lds_tables) {
+        const int lb = (int)s.lds_bytes;
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+    }
+}
+
+static uint64_t record_max(size_t max_hdr, uint64_t max_chrom, bool paired, uint32_t L) {
+    return max_hdr + n_digits(max_chrom) + 2 + (paired ? 2 : 0) + 1 + (uint64_t)L + 3 + L + 1;
+}
+
+// ---- illumina_ref_cpp (src/hts_illumina.cpp:589-649): everything the reference does on the calling
+// thread before the parallel region, plus device set-up.
+static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_illumina_args& a, SeedReader& seeds) {
+    setup_model(s, a);
+    const uint32_t L = s.tables.read_length;
+    const std::string barcode = (a.barcodes && a.n_barcodes > 0 && a.barcodes[0]) ? a.barcodes[0] : "";
+    check_barcode(barcode, L);
+    upload_genome(s, g, nullptr, 0);
     uint64_t min_chrom = ~0ULL, max_chrom = 0;
     size_t max_hdr = 0;
     const std::string gname = g.name ? g.name : "REF";
@@ -160,30 +303,26 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
         max_chrom = std::max<uint64_t>(max_chrom, g.chrom_lens[i]);
         max_hdr = std::max(max_hdr, 3 + gname.size() + std::strlen(g.chrom_names ? g.chrom_names[i] : ""));
     }
+    {
+        std::vector<uint8_t> blob;
+        std::vector<uint32_t> hoff(g.n_chroms + 1);
+        for (uint64_t i = 0; i < g.n_chroms; i++) {
+            hoff[i] = (uint32_t)blob.size();
+            std::string h = "@" + gname + "-" + (g.chrom_names ? g.chrom_names[i] : "") + "-";
+            blob.insert(blob.end(), h.begin(), h.end());
+        }
+        hoff[g.n_chroms] = (uint32_t)blob.size();
+        s.d_hdr_blob.upload(blob);
+        s.d_hdr_off.upload(hoff);
+    }
     const uint64_t frag_lb = std::min<uint64_t>(a.frag_len_min <= a.frag_len_max ? a.frag_len_min : a.frag_len_max, min_chrom);
     if (frag_lb < std::max<uint64_t>(barcode.size(), 1))
         throw Error(JK_ERR_UNSUPPORTED, "fragments shorter than the barcode (or empty) are not implemented on the GPU path");
 
     // ---- lanes, quotas, seeds: same order of seed consumption as src/hts.h:334-353
-    uint64_t T = a.n_threads ? a.n_threads : 1;
-    s.n_lanes_total = T;
-    s.lane_begin = a.lane_begin;
-    s.lane_end = a.lane_end ? a.lane_end : T;
-    if (s.lane_begin > s.lane_end || s.lane_end > T) throw Error(JK_ERR_ARG, "lane shard out of range");
-    s.n_shard = s.lane_end - s.lane_begin;
-    std::vector<uint64_t> per_lane = split_int(a.n_reads / s.n_ends, T);
-    for (uint64_t& v : per_lane) v *= s.n_ends;
-    if (per_lane[0] > 0xffffffffULL) throw Error(JK_ERR_UNSUPPORTED, "more than 2^32 reads per lane: raise n_threads");
-
-    SeedReader seeds{a.seeds};
-    std::vector<uint32_t> lane_seeds(s.n_shard * 8);
-    {
-        uint32_t w[8];
-        for (uint64_t t = 0; t < T; t++) {
-            seeds.take8(w);
-            if (t >= s.lane_begin && t < s.lane_end) std::memcpy(&lane_seeds[(t - s.lane_begin) * 8], w, sizeof(w));
-        }
-    }
+    std::vector<uint64_t> per_lane = plan_lanes(s, a, a.n_reads);
+    const uint64_t T = s.n_lanes_total;
+    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
     std::vector<uint64_t> lane_reads(s.n_shard);
     std::vector<uint32_t> chrom_reads((size_t)s.n_chroms * s.n_shard, 0);
     std::vector<double> chrom_probs(g.chrom_lens, g.chrom_lens + g.n_chroms);
@@ -206,115 +345,144 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
     }
     s.seed_words_used = seeds.pos;
 
-    // ---- pools: one region per lane, big enough for its quota of maximal records
-    const uint64_t rec_max = max_hdr + n_digits(max_chrom) + 2 + (s.paired ? 2 : 0) + 1 + (uint64_t)L + 3 + L + 1;
-    const uint64_t max_batch = a.max_batch_bytes ? a.max_batch_bytes : (8ULL << 30);
-    const uint64_t max_batch_lanes = 1ULL << 22;
-    // Pools are organised in tiles of 64 lanes (one wave); every lane of a tile gets the capacity of
-    // the tile's largest quota.  A batch is a run of whole tiles.
-    std::vector<uint64_t> pool_off;    // concatenation over batches of (n_tiles+1) relative offsets
-    uint64_t out_cap = 0, max_pool = 0;
-    uint32_t max_lanes = 0;
-    {
-        uint64_t l = 0;
-        while (l < s.n_shard) {
-            Batch b{l, 0, 0};
-            s.batch_pool_off_index.push_back(pool_off.size());
-            pool_off.push_back(0);
-            uint64_t used = 0;
-            while (l < s.n_shard && b.n_lanes < max_batch_lanes) {
-                const uint64_t tl = std::min<uint64_t>(64, s.n_shard - l);
-                uint64_t maxq = 0;
-                for (uint64_t k = 0; k < tl; k++) maxq = std::max(maxq, lane_reads[l + k] / s.n_ends);
-                const uint64_t cap = align_up(maxq * rec_max, 4) * 64;
-                if (b.n_lanes > 0 && used + cap > max_batch) break;
-                used += cap; pool_off.push_back(used); b.n_lanes += (uint32_t)tl; l += tl;
-            }
-            b.pool_bytes = used;
-            out_cap += used;
-            max_pool = std::max(max_pool, used);
-            max_lanes = std::max(max_lanes, b.n_lanes);
-            s.batches.push_back(b);
-        }
-    }
-    s.out_cap = out_cap;
-
-    // ---- device state
-    s.d_seeds.upload(lane_seeds);
-    s.d_lane_reads.upload(lane_reads);
-    s.d_chrom_reads.upload(chrom_reads);
-    s.d_pool_off.upload(pool_off);
-    s.d_info.upload(s.tables.info);
-    s.d_thresh.upload(s.tables.thresh);
-    s.d_quals.upload(s.tables.quals);
-    s.d_mm.upload(s.tables.mm_thresh);
-    for (uint32_t e = 0; e < s.n_ends; e++) {
-        s.d_pool[e].alloc(max_pool + 64);
-        s.d_out[e].alloc(out_cap + 64);
-        s.d_lane_bytes[e].alloc(s.n_shard * 8);
-        s.d_lane_off[e].alloc(s.n_shard * 8);
-        s.d_base[e].alloc((s.batches.size() + 1) * 8);
-    }
-    s.d_lane_made.alloc(s.n_shard * 8);
-    s.d_block_sums.alloc((max_lanes / SCAN_BLOCK + 2) * 8);
-    s.d_evw.alloc((size_t)s.n_ends * 4 * ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
-    s.d_err.alloc(4);
-
-    s.lds_bytes = (s.tables.thresh.size() + (s.tables.thresh.size() & 1)) * 8 + 256 * 8 + s.tables.info.size() * 4 + align_up(s.tables.quals.size() * 2, 16);
-    s.lds_tables = s.lds_bytes <= 150 * 1024;
-
     IlluminaKernelParams& P = s.kp;
-    P.g.seq = s.d_seq.as<uint8_t>();
-    P.g.chrom_off = s.d_chrom_off.as<uint64_t>();
-    P.g.chrom_len = s.d_chrom_len.as<uint64_t>();
-    P.g.hdr_blob = s.d_hdr_blob.as<uint8_t>();
-    P.g.hdr_off = s.d_hdr_off.as<uint32_t>();
-    P.g.n_chroms = s.n_chroms;
-    P.evw = s.d_evw.as<uint64_t>();
-    P.err = s.d_err.as<uint32_t>();
-    P.read_len = L; P.n_ends = s.n_ends; P.paired = s.paired; P.matepair = (s.paired && a.matepair) ? 1 : 0;
-    P.ev_words = ev_words;
-    P.frag_min = a.frag_len_min; P.frag_max = a.frag_len_max;
-    {   // gamma_distribution<double>::param_type::_M_initialize (random.tcc:2330-2346), alpha >= 1
-        const double a1 = a.frag_len_shape - 1.0 / 3.0;
-        P.gp.a1 = a1;
-        P.gp.a2 = 1.0 / std::sqrt(9.0 * a1);
-        P.gp.beta = a.frag_len_scale;
-    }
-    const double insp[2] = {a.ins_prob1, a.ins_prob2}, delp[2] = {a.del_prob1, a.del_prob2};
-    for (uint32_t r = 0; r < 2; r++) {
-        // u > (ins + del) -> match ; else u > ins -> deletion ; else insertion (hts_illumina.cpp:133-144)
-        Threshold tm = threshold_le(insp[r] + delp[r]);
-        Threshold td = threshold_le(insp[r]);
-        P.th_match[r] = tm.th; P.never_match[r] = tm.all;
-        P.th_del[r] = td.th; P.never_del[r] = td.all;
-    }
-    {   // dup < prob_dup (src/hts.h:265-266)
-        Threshold t = threshold_lt(a.prob_dup);
-        P.th_dup = t.th; P.dup_all = t.all;
-    }
-    P.pool_size = a.read_pool_size;
     P.bc_len = (uint32_t)barcode.size();
     std::memset(P.barcode, 0, sizeof(P.barcode));
-    for (size_t k = 0; k < barcode.size(); k++) {
-        const char c = barcode[k];
-        P.barcode[k] = c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : 4;
-    }
-    P.info = s.d_info.as<uint32_t>(); P.thresh = s.d_thresh.as<uint64_t>();
-    P.quals = s.d_quals.as<uint16_t>(); P.mm_thresh = s.d_mm.as<uint64_t>();
-    P.n_info = (uint32_t)s.tables.info.size(); P.n_entries = (uint32_t)s.tables.thresh.size();
+    for (size_t k = 0; k < barcode.size(); k++) P.barcode[k] = encode_base(barcode[k]);
+    plan_pools_and_alloc(s, a, lane_reads, record_max(max_hdr, max_chrom, s.paired, L), lane_seeds, chrom_reads);
+}
 
-    const size_t n_ev = 2 + 2 * s.batches.size() + 2;
-    s.events.resize(n_ev);
-    for (hipEvent_t& e : s.events) JK_HIP(hipEventCreate(&e));
+// ---- illumina_hap_cpp (src/hts_illumina.cpp:662-739), one set of output files (sep_files handled by
+// the caller: it opens one session per haplotype with one-hot probabilities, src/hts.h:512-552).
+static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illumina_args& a,
+                              const std::vector<double>& hap_probs, uint64_t n_reads, SeedReader& seeds) {
+    setup_model(s, a);
+    s.hap = true;
+    const uint32_t L = s.tables.read_length;
+    const uint64_t nh = hs.n_haps, nc = hs.ref.n_chroms;
+    if (nh == 0 || nc == 0) throw Error(JK_ERR_ARG, "haplotype set is empty");
+    if (nh * nc > 0x7fffffffULL) throw Error(JK_ERR_UNSUPPORTED, "too many (haplotype, chromosome) cells");
+    if (hap_probs.size() != nh) throw Error(JK_ERR_ARG, "haplotype_probs must have one entry per haplotype");
+    // barcodes: padded with "" to one per haplotype (src/hts_illumina.h:550)
+    std::vector<std::string> bcs(nh);
+    for (uint64_t h = 0; h < nh && h < a.n_barcodes; h++) bcs[h] = (a.barcodes && a.barcodes[h]) ? a.barcodes[h] : "";
+    size_t max_bc = 0;
+    for (const std::string& b : bcs) { check_barcode(b, L); max_bc = std::max(max_bc, b.size()); }
 
-    if (const char* e = std::getenv("JK_BLOCK")) s.block = std::atoi(e) == 512 ? 512 : 1024;
-    if (s.lds_tables) {
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 1, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 2, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 1, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_ref_kernel<true, 2, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s.lds_bytes));
+    // ---- mutation tables -> device form (see HapDev)
+    const uint64_t n_cells = nh * nc;
+    std::vector<uint64_t> cell_off(n_cells + 1, 0);
+    for (uint64_t k = 0; k < n_cells; k++) cell_off[k + 1] = cell_off[k] + hs.n_mut[k];
+    const uint64_t n_mut = cell_off[n_cells];
+    const uint64_t blob_len = n_mut ? hs.nuc_off[n_mut] : 0;
+    upload_genome(s, hs.ref, hs.nuc_blob, blob_len);          // sets s.nuc_base = offset of the blob in seq
+    std::vector<int64_t> ref_shift(n_mut);
+    std::vector<uint32_t> nuc_len(n_mut);
+    std::vector<uint64_t> nuc_dev_off(n_mut), new_pos(hs.new_pos, hs.new_pos + n_mut), cell_size(hs.chrom_size, hs.chrom_size + n_cells);
+    uint64_t min_chrom = ~0ULL, max_chrom = 0;
+    for (uint64_t k = 0; k < n_cells; k++) {
+        const uint64_t ref_len = hs.ref.chrom_lens[k % nc];
+        min_chrom = std::min(min_chrom, cell_size[k]);
+        max_chrom = std::max(max_chrom, cell_size[k]);
+        for (uint64_t m = cell_off[k]; m < cell_off[k + 1]; m++) {
+            // size_modifier (src/hap_classes.h:314-333)
+            int64_t smod = (m + 1 < cell_off[k + 1]) ? (int64_t)(hs.new_pos[m + 1] - hs.old_pos[m + 1])
+                                                     : (int64_t)(cell_size[k] - ref_len);
+            smod += (int64_t)(hs.old_pos[m] - hs.new_pos[m]);
+            const uint64_t have = hs.nuc_off[m + 1] - hs.nuc_off[m];
+            if (m > cell_off[k] && hs.new_pos[m] <= hs.new_pos[m - 1]) throw Error(JK_ERR_ARG, "mutation new_pos must be strictly increasing within a chromosome");
+            if (smod >= 0 && have < (uint64_t)smod + 1) throw Error(JK_ERR_ARG, "mutation has fewer nucleotides than its size modifier needs");
+            if (smod + 1 > 0x7fffffffLL) throw Error(JK_ERR_UNSUPPORTED, "insertion longer than 2^31 bases");
+            nuc_len[m] = smod >= 0 ? (uint32_t)(smod + 1) : 0u;
+            nuc_dev_off[m] = s.nuc_base + hs.nuc_off[m];
+            ref_shift[m] = (int64_t)hs.old_pos[m] - smod - (int64_t)hs.new_pos[m];
+            // the reference run after this mutation must stay inside the chromosome
+            const uint64_t run_end = (m + 1 < cell_off[k + 1]) ? hs.new_pos[m + 1] : cell_size[k];
+            const int64_t last_ref = (int64_t)run_end - 1 + ref_shift[m];
+            if (run_end > hs.new_pos[m] + nuc_len[m] && (last_ref < 0 || (uint64_t)last_ref >= ref_len))
+                throw Error(JK_ERR_ARG, "mutation table points outside the reference chromosome");
+        }
     }
+    s.d_cell_off.upload(cell_off);
+    s.d_new_pos.upload(new_pos);
+    s.d_ref_shift.upload(ref_shift);
+    s.d_nuc_len.upload(nuc_len);
+    s.d_nuc_off.upload(nuc_dev_off);
+    s.d_cell_size.upload(cell_size);
+    {
+        std::vector<uint8_t> blob(nh * JK_MAX_BARCODE, 0);
+        std::vector<uint32_t> blen(nh);
+        for (uint64_t h = 0; h < nh; h++) {
+            blen[h] = (uint32_t)bcs[h].size();
+            for (size_t k = 0; k < bcs[h].size(); k++) blob[h * JK_MAX_BARCODE + k] = encode_base(bcs[h][k]);
+        }
+        s.d_bc_blob.upload(blob);
+        s.d_bc_len.upload(blen);
+    }
+    size_t max_hdr = 0;
+    {   // "@<haplotype>-<chromosome>-" per cell
+        std::vector<uint8_t> blob;
+        std::vector<uint32_t> hoff(n_cells + 1);
+        for (uint64_t k = 0; k < n_cells; k++) {
+            hoff[k] = (uint32_t)blob.size();
+            std::string h = std::string("@") + (hs.hap_names ? hs.hap_names[k / nc] : "") + "-" +
+                            (hs.ref.chrom_names ? hs.ref.chrom_names[k % nc] : "") + "-";
+            max_hdr = std::max(max_hdr, h.size());
+            blob.insert(blob.end(), h.begin(), h.end());
+        }
+        hoff[n_cells] = (uint32_t)blob.size();
+        s.d_hdr_blob.upload(blob);
+        s.d_hdr_off.upload(hoff);
+    }
+    const uint64_t frag_lb = std::min<uint64_t>(a.frag_len_min <= a.frag_len_max ? a.frag_len_min : a.frag_len_max, min_chrom);
+    if (frag_lb < std::max<uint64_t>(max_bc, 1))
+        throw Error(JK_ERR_UNSUPPORTED, "fragments shorter than the barcode (or empty) are not implemented on the GPU path");
+
+    // ---- lanes, quotas, seeds.  IlluminaHaplotypes::add_n_reads (src/hts_illumina.h:620-644) per lane:
+    // reads_per_group over haplotypes, then per haplotype reads_per_group over its chromosomes, then
+    // each read maker's own add_n_reads (halves the pair count again when paired; its result is never
+    // read by the haplotype path, but it consumes 8 seed words when it has reads).
+    std::vector<uint64_t> per_lane = plan_lanes(s, a, n_reads);
+    const uint64_t T = s.n_lanes_total;
+    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
+    std::vector<uint64_t> lane_reads(s.n_shard);
+    std::vector<uint32_t> vc((size_t)n_cells * s.n_shard, 0);
+    std::vector<std::vector<double>> chrom_probs(nh, std::vector<double>(nc));
+    for (uint64_t h = 0; h < nh; h++) for (uint64_t c = 0; c < nc; c++) chrom_probs[h][c] = (double)cell_size[h * nc + c];
+    for (uint64_t t = 0; t < T; t++) {
+        uint64_t n = per_lane[t];
+        if (s.paired) n /= 2;
+        const bool mine = t >= s.lane_begin && t < s.lane_end;
+        std::vector<uint64_t> hap_reads = reads_per_group(n, hap_probs, seeds);
+        for (uint64_t h = 0; h < nh; h++) {
+            if (mine) {
+                std::vector<uint64_t> cr = reads_per_group(hap_reads[h], chrom_probs[h], seeds);
+                for (uint64_t c = 0; c < nc; c++)
+                    vc[(size_t)(h * nc + c) * s.n_shard + (t - s.lane_begin)] = (uint32_t)(cr[c] * (s.paired ? 2 : 1));
+            } else if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }
+        }
+        for (uint64_t h = 0; h < nh; h++) {
+            uint64_t m = hap_reads[h];
+            if (s.paired) m /= 2;
+            if (m > 0) { uint32_t w[8]; seeds.take8(w); }
+        }
+        if (mine) lane_reads[t - s.lane_begin] = per_lane[t];
+    }
+    s.seed_words_used = seeds.pos;
+
+    IlluminaKernelParams& P = s.kp;
+    P.bc_len = 0;
+    std::memset(P.barcode, 0, sizeof(P.barcode));
+    P.h.cell_mut_off = s.d_cell_off.as<uint64_t>();
+    P.h.new_pos = s.d_new_pos.as<uint64_t>();
+    P.h.ref_shift = s.d_ref_shift.as<int64_t>();
+    P.h.nuc_len = s.d_nuc_len.as<uint32_t>();
+    P.h.nuc_off = s.d_nuc_off.as<uint64_t>();
+    P.h.cell_size = s.d_cell_size.as<uint64_t>();
+    P.h.bc_blob = s.d_bc_blob.as<uint8_t>();
+    P.h.bc_len = s.d_bc_len.as<uint32_t>();
+    P.h.n_haps = (uint32_t)nh;
+    plan_pools_and_alloc(s, a, lane_reads, record_max(max_hdr, max_chrom, s.paired, L), lane_seeds, vc);
 }
 
 static void launch_generate(jk_session& s) {
@@ -340,16 +508,16 @@ static void launch_generate(jk_session& s) {
         }
         P.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
         P.chrom_stride = (uint32_t)s.n_shard;
-        const uint32_t block = (uint32_t)s.block;
+        const uint32_t block = 1024;
         const uint32_t grid = (B.n_lanes + block - 1) / block;
         JK_HIP(hipEventRecord(s.events[ev++], s.stream));
-#define JK_LAUNCH(LDS, NE, BLK, SH) hipLaunchKernelGGL((illumina_ref_kernel<LDS, NE, BLK>), dim3(grid), dim3(block), SH, s.stream, P)
+#define JK_LAUNCH(LDS, NE, HAP, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, 1024, HAP>), dim3(grid), dim3(block), SH, s.stream, P)
         if (s.lds_tables) {
-            if (block == 1024) { if (s.n_ends == 2) JK_LAUNCH(true, 2, 1024, s.lds_bytes); else JK_LAUNCH(true, 1, 1024, s.lds_bytes); }
-            else               { if (s.n_ends == 2) JK_LAUNCH(true, 2, 512, s.lds_bytes);  else JK_LAUNCH(true, 1, 512, s.lds_bytes); }
+            if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(true, 2, true, s.lds_bytes); else JK_LAUNCH(true, 1, true, s.lds_bytes); }
+            else       { if (s.n_ends == 2) JK_LAUNCH(true, 2, false, s.lds_bytes); else JK_LAUNCH(true, 1, false, s.lds_bytes); }
         } else {
-            if (block == 1024) { if (s.n_ends == 2) JK_LAUNCH(false, 2, 1024, 0); else JK_LAUNCH(false, 1, 1024, 0); }
-            else               { if (s.n_ends == 2) JK_LAUNCH(false, 2, 512, 0);  else JK_LAUNCH(false, 1, 512, 0); }
+            if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(false, 2, true, 0); else JK_LAUNCH(false, 1, true, 0); }
+            else       { if (s.n_ends == 2) JK_LAUNCH(false, 2, false, 0); else JK_LAUNCH(false, 1, false, 0); }
         }
 #undef JK_LAUNCH
         JK_HIP(hipGetLastError());
@@ -485,13 +653,27 @@ int jk_illumina_ref_open(const jk_ref_genome* genome, const jk_illumina_args* ar
     return guarded([&] {
         if (!genome || !args || !out) throw Error(JK_ERR_ARG, "NULL argument");
         std::unique_ptr<jk_session> s(new jk_session());
-        open_illumina_ref(*s, *genome, *args);
+        SeedReader seeds{args->seeds};
+        open_illumina_ref(*s, *genome, *args, seeds);
         *out = s.release();
     });
 }
 
-int jk_illumina_hap_open(const jk_hap_set*, const jk_illumina_args*, jk_session**) {
-    return guarded([&] { throw Error(JK_ERR_UNSUPPORTED, "haplotype sequencing is not implemented yet on the GPU path"); });
+static std::vector<double> hap_probs_of(const jk_hap_set& hs, const jk_illumina_args& a) {
+    // R passes rep(1, n_haps) when haplotype_probs is NULL (R/hts_illumina.R:665-667)
+    if (!a.haplotype_probs) return std::vector<double>(hs.n_haps, 1.0);
+    return std::vector<double>(a.haplotype_probs, a.haplotype_probs + hs.n_haps);
+}
+
+int jk_illumina_hap_open(const jk_hap_set* haps, const jk_illumina_args* args, jk_session** out) {
+    return guarded([&] {
+        if (!haps || !args || !out) throw Error(JK_ERR_ARG, "NULL argument");
+        if (args->sep_files) throw Error(JK_ERR_UNSUPPORTED, "sep_files needs one session per haplotype: use jk_illumina_hap");
+        std::unique_ptr<jk_session> s(new jk_session());
+        SeedReader seeds{args->seeds};
+        open_illumina_hap(*s, *haps, *args, hap_probs_of(*haps, *args), args->n_reads, seeds);
+        *out = s.release();
+    });
 }
 
 int jk_session_generate(jk_session* s) {
@@ -562,14 +744,33 @@ int jk_illumina_ref(const jk_ref_genome* genome, const jk_illumina_args* args) {
 }
 
 int jk_illumina_hap(const jk_hap_set* haps, const jk_illumina_args* args) {
-    jk_session* s = nullptr;
-    int rc = jk_illumina_hap_open(haps, args, &s);
-    if (rc == JK_OK) rc = jk_session_generate(s);
-    if (rc == JK_OK) rc = jk_session_write(s);
-    std::string keep = g_last_error;
-    jk_session_close(s);
-    g_last_error = keep;
-    return rc;
+    return guarded([&] {
+        if (!haps || !args) throw Error(JK_ERR_ARG, "NULL argument");
+        SeedReader seeds{args->seeds};
+        const std::vector<double> probs = hap_probs_of(*haps, *args);
+        if (!args->sep_files) {
+            std::unique_ptr<jk_session> s(new jk_session());
+            open_illumina_hap(*s, *haps, *args, probs, args->n_reads, seeds);
+            launch_generate(*s);
+            write_files(*s);
+            return;
+        }
+        // write_reads_cpp_sep_files_ (src/hts.h:512-552): reads per file, then one run per haplotype with
+        // one-hot haplotype probabilities and prefix <out_prefix>_<haplotype>
+        const uint64_t n_ends = args->paired ? 2 : 1;
+        std::vector<uint64_t> per_file = reads_per_group(args->n_reads / n_ends, probs, seeds);
+        for (uint64_t& v : per_file) v *= n_ends;
+        for (uint64_t h = 0; h < haps->n_haps; h++) {
+            if (args->abort_flag && *args->abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
+            std::vector<double> one_hot(haps->n_haps, 0.0);
+            one_hot[h] = 1;
+            std::unique_ptr<jk_session> s(new jk_session());
+            open_illumina_hap(*s, *haps, *args, one_hot, per_file[h], seeds);
+            s->out_prefix += std::string("_") + (haps->hap_names ? haps->hap_names[h] : "");
+            launch_generate(*s);
+            write_files(*s);
+        }
+    });
 }
 
 void jk_split_int(uint64_t x, uint64_t n, uint64_t* out) {
@@ -592,8 +793,32 @@ void jk_alias_build(const double* probs, uint64_t n, double* Prob, uint64_t* Ali
     for (uint64_t i = 0; i < n; i++) { Prob[i] = t.prob[i]; Alias[i] = t.alias[i]; }
 }
 
-int jk_hap_chrom_full(const jk_hap_set*, uint64_t, uint64_t, char*, uint64_t) {
-    return guarded([&] { throw Error(JK_ERR_UNSUPPORTED, "not implemented yet"); });
+// HapChrom::get_chrom_full (src/hap_classes.cpp:80-116) on the host, from the flat view: walks the
+// mutations in order and copies reference runs and mutation bytes.
+int jk_hap_chrom_full(const jk_hap_set* hs, uint64_t hap, uint64_t chrom, char* out, uint64_t cap) {
+    return guarded([&] {
+        if (!hs || hap >= hs->n_haps || chrom >= hs->ref.n_chroms) throw Error(JK_ERR_ARG, "bad haplotype/chromosome index");
+        const uint64_t nc = hs->ref.n_chroms, cell = hap * nc + chrom;
+        uint64_t m0 = 0;
+        for (uint64_t k = 0; k < cell; k++) m0 += hs->n_mut[k];
+        const uint64_t m1 = m0 + hs->n_mut[cell];
+        const uint64_t size = hs->chrom_size[cell], ref_len = hs->ref.chrom_lens[chrom];
+        if (cap < size) throw Error(JK_ERR_ARG, "destination too small");
+        const char* ref = hs->ref.chrom_seqs[chrom];
+        uint64_t pos = 0;
+        const uint64_t first = m0 < m1 ? hs->new_pos[m0] : size;
+        for (; pos < first; pos++) out[pos] = ref[pos];
+        for (uint64_t m = m0; m < m1; m++) {
+            int64_t smod = (m + 1 < m1) ? (int64_t)(hs->new_pos[m + 1] - hs->old_pos[m + 1]) : (int64_t)(size - ref_len);
+            smod += (int64_t)(hs->old_pos[m] - hs->new_pos[m]);
+            const uint64_t end = (m + 1 < m1) ? hs->new_pos[m + 1] : size;
+            for (; pos < end; pos++) {
+                const uint64_t ind = pos - hs->new_pos[m];
+                if ((int64_t)ind > smod) out[pos] = ref[ind + hs->old_pos[m] - smod];
+                else out[pos] = hs->nuc_blob[hs->nuc_off[m] + ind];
+            }
+        }
+    });
 }
 
 void jk_eval_set_gamma(double shape, double scale) { g_eval_shape = shape; g_eval_scale = scale; }

@@ -48,8 +48,30 @@ struct GenomeDev {
     uint32_t n_chroms;
 };
 
+// Haplotypes: the mutation tables of all (haplotype, chromosome) cells, cell = hap * n_chroms + chrom
+// (read side of AllMutations/HapChrom, /root/reference/src/hap_classes.h:100-258,314-333,439-455).
+// For mutation m (absolute index) covering haplotype positions [new_pos[m], new_pos[m+1]):
+//   pos - new_pos[m] <  nuc_len[m]  ->  seq[nuc_off[m] + pos - new_pos[m]]     (substituted / inserted bytes)
+//   otherwise                       ->  reference chromosome at pos + ref_shift[m]
+// which is get_char_ with size_modifier folded in on the host (nuc_len = max(size_mod + 1, 0),
+// ref_shift = old_pos - size_mod - new_pos).  Positions before a cell's first mutation read the
+// reference unshifted.  The nucleotide bytes live in the same (encoded) buffer as the genome.
+struct HapDev {
+    const uint64_t* cell_mut_off;  // [n_cells + 1]
+    const uint64_t* new_pos;       // [n_mut]
+    const int64_t* ref_shift;      // [n_mut]
+    const uint32_t* nuc_len;       // [n_mut]
+    const uint64_t* nuc_off;       // [n_mut] offset in GenomeDev::seq
+    const uint64_t* cell_size;     // [n_cells] haplotype chromosome sizes
+    const uint8_t* bc_blob;        // [n_haps][JK_MAX_BARCODE] encoded barcodes
+    const uint32_t* bc_len;        // [n_haps]
+    uint32_t n_haps;
+};
+
 struct IlluminaKernelParams {
     GenomeDev g;
+    HapDev h;                    // used by the HAP kernels only; then g.hdr_off is indexed by cell and
+                                 // chrom_reads holds n_reads_vc: [cell * chrom_stride + lane]
     // lanes of this launch
     uint32_t n_lanes;
     const uint32_t* seeds;       // [n_lanes * 8] sub-seed words
@@ -136,11 +158,51 @@ struct TabPtrs {
     const uint4* info4; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm;
 };
 
+struct HapSeg { uint64_t addr, begin, end; };   // haplotype positions [begin, end) lie contiguously at seq[addr + (pos - hpos)]
+
+// Which contiguous piece of the (encoded) buffer serves haplotype position hpos of `cell`?  `m` is the
+// cell-relative index of the last mutation with new_pos <= hpos (-1: none) and is updated in place.
+__device__ __forceinline__ HapSeg hap_resolve(const HapDev& H, uint64_t chrom_off, uint32_t cell, int64_t& m, uint64_t hpos) {
+    const uint64_t mo = H.cell_mut_off[cell];
+    const int64_t n = (int64_t)(H.cell_mut_off[cell + 1] - mo);
+    while (m + 1 < n && H.new_pos[mo + m + 1] <= hpos) m++;
+    while (m >= 0 && H.new_pos[mo + m] > hpos) m--;
+    HapSeg sg;
+    if (m < 0) {
+        sg.begin = 0; sg.end = n > 0 ? H.new_pos[mo] : H.cell_size[cell];
+        sg.addr = chrom_off + hpos;
+    } else {
+        const uint64_t np = H.new_pos[mo + m];
+        const uint64_t nl = H.nuc_len[mo + m];
+        if (hpos - np < nl) {
+            sg.begin = np; sg.end = np + nl;
+            sg.addr = H.nuc_off[mo + m] + (hpos - np);
+        } else {
+            sg.begin = np + nl; sg.end = (m + 1 < n) ? H.new_pos[mo + m + 1] : H.cell_size[cell];
+            sg.addr = chrom_off + (uint64_t)((int64_t)hpos + H.ref_shift[mo + m]);
+        }
+    }
+    return sg;
+}
+// last mutation of `cell` with new_pos <= hpos (cell-relative, -1 if none): binary search
+__device__ __forceinline__ int64_t hap_search(const HapDev& H, uint32_t cell, uint64_t hpos) {
+    const uint64_t mo = H.cell_mut_off[cell];
+    int64_t lo = 0, hi = (int64_t)(H.cell_mut_off[cell + 1] - mo);     // first index with new_pos > hpos
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (H.new_pos[mo + mid] <= hpos) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+
 // NE = number of read ends (1 single-end, 2 paired); BLOCK = workgroup size (1024 -> 4 waves/SIMD and a
-// 128-VGPR budget, 512 -> 2 waves/SIMD and 256 VGPRs; with the tables in LDS one workgroup fits per CU)
-template <bool LDS_TAB, uint32_t NE, int BLOCK>
+// 128-VGPR budget, 512 -> 2 waves/SIMD and 256 VGPRs; with the tables in LDS one workgroup fits per CU).
+// HAP = sequence a set of haplotypes (IlluminaHaplotypes, src/hts_illumina.h:509-675, .cpp:495-558):
+// the lane walks (haplotype, chromosome) cells in order with per-cell quotas and reads bases through
+// the mutation tables instead of materialising each haplotype chromosome as the reference does.
+template <bool LDS_TAB, uint32_t NE, int BLOCK, bool HAP>
 __global__ void __launch_bounds__(BLOCK)
-illumina_ref_kernel(IlluminaKernelParams P) {
+illumina_kernel(IlluminaKernelParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     TabPtrs T;
     if (LDS_TAB) {
@@ -164,14 +226,18 @@ illumina_ref_kernel(IlluminaKernelParams P) {
     rng.e = jk_pcg_seed(P.seeds + (size_t)lane * 8);
     jk_gamma_state gst; gst.saved = 0.0; gst.saved_available = 0;
 
-    const uint32_t L = P.read_len, bc = P.bc_len;
+    const uint32_t L = P.read_len;
+    uint32_t bc = P.bc_len;                      // HAP: per haplotype, reloaded when the cursor moves
     const uint64_t quota = P.lane_reads[lane];
     uint64_t made = 0, in_pool = 0;
 
     // chromosome cursor: the reference rescans from chromosome 0 for the first non-zero quota
     // (src/hts_illumina.cpp:199-200); quotas only ever decrease, so a monotone cursor is the same.
+    // HAP: `ci` is the cell index hap * n_chroms + chrom, `n_cells` the number of cells.
+    const uint32_t n_cells = HAP ? P.h.n_haps * P.g.n_chroms : P.g.n_chroms;
     uint32_t ci = 0;
-    uint64_t ccnt = P.g.n_chroms ? P.chrom_reads[lane] : 0;
+    uint64_t ccnt = n_cells ? P.chrom_reads[lane] : 0;
+    uint32_t cur_hap = 0xffffffffu;
 
     const uint32_t tile = lane >> 6;
     const uint64_t tile_off = P.pool_off[tile];
@@ -198,9 +264,19 @@ illumina_ref_kernel(IlluminaKernelParams P) {
     while (made < quota) {
         if (!is_dup) {
             // ---- chrom_indels_frag: chromosome, fragment length, fragment start (hts_illumina.cpp:192-217)
-            while (ci < P.g.n_chroms && ccnt == 0) { ci++; if (ci < P.g.n_chroms) ccnt = P.chrom_reads[(size_t)ci * P.chrom_stride + lane]; }
-            if (ci >= P.g.n_chroms) { made = quota; break; }         // `finished`
-            const uint64_t chrom_len = P.g.chrom_len[ci];
+            // (HAP: IlluminaHaplotypes::one_read's cursor search, hts_illumina.cpp:505-525 -- the first cell at
+            //  or after the current one with reads left)
+            while (ci < n_cells && ccnt == 0) { ci++; if (ci < n_cells) ccnt = P.chrom_reads[(size_t)ci * P.chrom_stride + lane]; }
+            if (ci >= n_cells) { made = quota; break; }         // `finished`
+            if (HAP) {
+                const uint32_t hap = ci / P.g.n_chroms;
+                if (hap != cur_hap) {       // a new IlluminaOneHaplotype: its own gamma state and barcode
+                    cur_hap = hap;
+                    gst.saved = 0.0; gst.saved_available = 0;
+                    bc = P.h.bc_len[hap];
+                }
+            }
+            const uint64_t chrom_len = HAP ? P.h.cell_size[ci] : P.g.chrom_len[ci];
             double gl = jk_gamma(P.gp, gst, rng);
             frag_len = (uint64_t)gl;
             if (frag_len < P.frag_min) frag_len = P.frag_min;
@@ -305,10 +381,11 @@ illumina_ref_kernel(IlluminaKernelParams P) {
             // bytes are consumed low byte first from an 8-byte register chunk; for the reverse strand
             // the chunk is byte-swapped and complemented when it is loaded.
             const uint8_t* const gseq = P.g.seq;
-            uint64_t gaddr;          // byte address (index into gseq) of the NEXT chunk to load
-            uint64_t gbuf; uint32_t gcnt;
-            {
-                const uint64_t a0 = P.g.chrom_off[ci] + (reverse ? (start + sp - 1 - bc) : start);
+            const uint64_t chrom_off = P.g.chrom_off[HAP ? ci % P.g.n_chroms : ci];
+            const uint8_t* const bcode = HAP ? P.h.bc_blob + (size_t)cur_hap * JK_MAX_BARCODE : P.barcode;
+            uint64_t gaddr = 0;      // byte address (index into gseq) of the NEXT chunk to load
+            uint64_t gbuf = 0; uint32_t gcnt = 0;
+            auto src_init = [&](uint64_t a0) {      // position the reader on byte a0, moving down if reverse
                 const uint64_t ch = a0 & ~7ULL;
                 uint64_t v = *reinterpret_cast<const uint64_t*>(gseq + ch);
                 const uint32_t k = (uint32_t)a0 & 7u;
@@ -319,8 +396,25 @@ illumina_ref_kernel(IlluminaKernelParams P) {
                 } else {
                     gbuf = v >> (8u * k); gcnt = 8u - k; gaddr = ch + 8;
                 }
-            }
-            auto src_next = [&]() -> uint32_t {
+            };
+            // HAP: the read is served segment by segment (reference runs and mutation bytes);
+            // seg_end_pp = first source position that is NOT in the current segment
+            uint32_t seg_end_pp = 0xffffffffu;
+            int64_t mcur = -1;
+            auto seg_enter = [&](uint32_t pp) {     // pp >= bc
+                const uint64_t hpos = reverse ? (start + sp - 1 - pp) : (start + pp - bc);
+                if (HAP) {
+                    const HapSeg sg = hap_resolve(P.h, chrom_off, ci, mcur, hpos);
+                    src_init(sg.addr);
+                    const uint64_t avail = reverse ? (hpos - sg.begin + 1) : (sg.end - hpos);
+                    seg_end_pp = avail >= (uint64_t)(0xffffffffu - pp) ? 0xffffffffu : pp + (uint32_t)avail;
+                } else {
+                    src_init(chrom_off + hpos);
+                }
+            };
+            if (HAP) mcur = hap_search(P.h, ci, reverse ? (start + sp - 1 - bc) : start);
+            if (sp > bc) seg_enter(bc);
+            auto src_next = [&]() -> uint32_t {    // next base of the current segment
                 const uint32_t c = (uint32_t)gbuf & 0xffu;
                 gbuf >>= 8;
                 if (--gcnt == 0) {
@@ -333,6 +427,10 @@ illumina_ref_kernel(IlluminaKernelParams P) {
                     gbuf = v; gcnt = 8;
                 }
                 return c;
+            };
+            auto src_take = [&](uint32_t pp) -> uint32_t {     // slow-path form: may have to change segment first
+                if (HAP && pp >= seg_end_pp) seg_enter(pp);
+                return src_next();
             };
             // first position of (ins|del) at or after pp, or "none"
             auto next_event = [&](uint32_t pp) -> uint32_t {
@@ -348,7 +446,11 @@ illumina_ref_kernel(IlluminaKernelParams P) {
             uint32_t pp = 0;
             // `nes`: the next source position that needs the slow path (barcode, deletion, insertion);
             // 0 forces it for the next base (pending inserted base).
-            uint32_t nes = bc ? 0u : (ev_any ? next_event(0) : 0xffffffffu);
+            auto next_slow = [&](uint32_t pp) -> uint32_t {
+                uint32_t e = ev_any ? next_event(pp) : 0xffffffffu;
+                return (HAP && seg_end_pp < e) ? seg_end_pp : e;
+            };
+            uint32_t nes = bc ? 0u : next_slow(0);
             bool pending = false; uint32_t pend_base = 0;
             const uint32_t info_base = i * L;
             for (uint32_t op = 0; op < n_out; op++) {
@@ -365,10 +467,10 @@ illumina_ref_kernel(IlluminaKernelParams P) {
                             const uint32_t w = pp >> 6, bit = pp & 63u;
                             const bool deleted = w < W && ((ev >> (16 + w)) & 1u) && ((*evaddr(i, 1, w) >> bit) & 1ULL);
                             if (!deleted) break;
-                            if (pp >= bc) (void)src_next();
+                            if (pp >= bc) (void)src_take(pp);
                             pp++;
                         }
-                        c = (pp < bc) ? (uint32_t)P.barcode[pp] : src_next();
+                        c = (pp < bc) ? (uint32_t)bcode[pp] : src_take(pp);
                         const uint32_t w = pp >> 6, bit = pp & 63u;
                         if (w < W && ((ev >> w) & 1u) && ((*evaddr(i, 0, w) >> bit) & 1ULL)) {
                             pending = true;
@@ -376,7 +478,7 @@ illumina_ref_kernel(IlluminaKernelParams P) {
                         }
                         pp++;
                     }
-                    nes = pending ? 0u : (pp < bc ? pp : (ev_any ? next_event(pp) : 0xffffffffu));
+                    nes = pending ? 0u : (pp < bc ? pp : next_slow(pp));
                 }
                 uint32_t q, ch;
                 if (c < 4u) {
@@ -408,7 +510,8 @@ illumina_ref_kernel(IlluminaKernelParams P) {
             o = oq;                    // the next record continues where the quality stream stopped
             reverse = !reverse;
         }
-        // quota bookkeeping (hts_illumina.cpp:404-406)
+        // quota bookkeeping: reference genome hts_illumina.cpp:404-406; haplotypes :532-533 (one_read)
+        // and :554-555 (re_read) -- the same "decrement, never below zero" for 1 or 2 ends
         ccnt = (ccnt < NE) ? 0 : ccnt - NE;
 
         // ---- ReadWriterOneThread::create_reads tail (src/hts.h:263-278)

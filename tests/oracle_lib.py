@@ -158,3 +158,70 @@ def illumina_ref(genome, *, paired, matepair=False, n_reads, prob_dup, n_threads
     r1 = _take(o1, l1.value)
     r2 = _take(o2, l2.value) if paired else None
     return r1, r2, used.value
+
+
+def _hap_view(hs):
+    """OrcHapSet struct + keep-alive list from a jackalope_amd.genome.HapSet."""
+    nh, nc = hs.n_haps(), hs.ref.n_chroms()
+    chrom_size = np.zeros(nh * nc, dtype=np.uint64)
+    n_mut = np.zeros(nh * nc, dtype=np.uint64)
+    old_pos, new_pos, nuc_off, blob = [], [], [0], []
+    for h in range(nh):
+        for c in range(nc):
+            cell = hs.cells[h][c]
+            chrom_size[h * nc + c] = cell["chrom_size"]
+            n_mut[h * nc + c] = len(cell["new_pos"])
+            old_pos += list(cell["old_pos"])
+            new_pos += list(cell["new_pos"])
+            for s in cell["nucleos"]:
+                blob.append(s.encode() if isinstance(s, str) else bytes(s))
+                nuc_off.append(nuc_off[-1] + len(blob[-1]))
+    old_pos = np.asarray(old_pos, dtype=np.uint64)
+    new_pos = np.asarray(new_pos, dtype=np.uint64)
+    nuc_off = np.asarray(nuc_off, dtype=np.uint64)
+    blob = np.frombuffer(b"".join(blob) + b"\0", dtype=np.uint8)
+    v = OrcHapSet()
+    v.n_haps, v.n_chroms = nh, nc
+    hn = (C.c_char_p * nh)(*[x.encode() for x in hs.names])
+    cn = (C.c_char_p * nc)(*[x.encode() for x in hs.ref.names])
+    rs = (C.c_void_p * nc)(*[s.ctypes.data for s in hs.ref.seqs])
+    rl = (C.c_uint64 * nc)(*hs.ref.sizes())
+    v.hap_names, v.chrom_names, v.ref_seqs, v.ref_lens = hn, cn, rs, rl
+    v.chrom_size, v.n_mut = chrom_size.ctypes.data, n_mut.ctypes.data
+    v.old_pos, v.new_pos, v.nuc_off, v.nuc_blob = old_pos.ctypes.data, new_pos.ctypes.data, nuc_off.ctypes.data, blob.ctypes.data
+    return v, [hn, cn, rs, rl, chrom_size, n_mut, old_pos, new_pos, nuc_off, blob]
+
+
+def hap_chrom_full(hs, hap, chrom):
+    """HapChrom::get_chrom_full through the oracle."""
+    v, keep = _hap_view(hs)
+    o, n = C.c_void_p(), C.c_uint64()
+    rc = lib().orc_hap_chrom_full(C.byref(v), C.c_uint64(hap), C.c_uint64(chrom), C.byref(o), C.byref(n))
+    if rc != 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+    return _take(o, n.value)
+
+
+def illumina_hap(hs, *, hap_probs, paired, matepair=False, n_reads, prob_dup, n_threads, read_pool_size, shape, scale,
+                 fmin, fmax, prof1, prof2=None, ins1, del1, ins2=0.0, del2=0.0, barcodes=(), words,
+                 thread_begin=0, thread_end=0, discard=False, thread_bytes=None):
+    """Oracle run of illumina_hap_cpp (sep_files = FALSE)."""
+    a, keep = _args(paired, matepair, n_reads, prob_dup, n_threads, read_pool_size, shape, scale, fmin, fmax, prof1,
+                    prof2, ins1, del1, ins2, del2, words)
+    a.thread_begin, a.thread_end, a.discard = int(thread_begin), int(thread_end), int(bool(discard))
+    tb = [np.zeros(int(n_threads), dtype=np.uint64), np.zeros(int(n_threads), dtype=np.uint64)]
+    a.thread_bytes1, a.thread_bytes2 = tb[0].ctypes.data, tb[1].ctypes.data
+    if thread_bytes is not None:
+        thread_bytes[0], thread_bytes[1] = tb[0], tb[1]
+    v, keep2 = _hap_view(hs)
+    hp = np.ascontiguousarray(hap_probs, dtype=np.float64)
+    bcs = (C.c_char_p * max(len(barcodes), 1))(*[b.encode() for b in barcodes])
+    o1, o2 = C.c_void_p(), C.c_void_p()
+    l1, l2, used = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = lib().orc_illumina_hap(C.byref(v), hp.ctypes.data_as(C.c_void_p), C.byref(a), bcs, C.c_uint64(len(barcodes)),
+                                C.byref(o1), C.byref(l1), C.byref(o2), C.byref(l2), C.byref(used))
+    if rc != 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+    r1 = _take(o1, l1.value)
+    r2 = _take(o2, l2.value) if paired else None
+    return r1, r2, used.value

@@ -1,0 +1,135 @@
+"""GPU parity for illumina() on haplotypes (illumina_hap_cpp, src/hts_illumina.cpp:662-739): the HIP
+path reads bases through the device mutation tables, the oracle materialises each haplotype chromosome
+with get_chrom_full exactly as the reference does -- FASTQ bytes must be identical."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import job, first_diff, fastq_records
+from jackalope_amd.genome import random_haplotypes, HapSet
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_hap(O, hs, p1, p2, words, n_reads, T, j, hap_probs, barcodes):
+    L = p1.read_length
+    fmin = j["frag_len_min"] if j["frag_len_min"] is not None else L
+    fmax = j["frag_len_max"] if j["frag_len_max"] is not None else 2 ** 32 - 1
+    paired = j["paired"] or j["matepair"]
+    return O.illumina_hap(hs, hap_probs=hap_probs, paired=paired, matepair=j["matepair"], n_reads=n_reads,
+                          prob_dup=j["prob_dup"], n_threads=T, read_pool_size=j["read_pool_size"],
+                          shape=(j["frag_mean"] / j["frag_sd"]) ** 2, scale=j["frag_sd"] ** 2 / j["frag_mean"],
+                          fmin=fmin, fmax=fmax, prof1=p1, prof2=p2, ins1=j["ins_prob1"], del1=j["del_prob1"],
+                          ins2=j["ins_prob2"], del2=j["del_prob2"], barcodes=barcodes, words=words)
+
+
+def hip_hap(ja, hs, read_length, words, n_reads, T, j, hap_probs, barcodes, **extra):
+    s = ja.illumina(hs, None, n_reads, read_length, j["paired"], frag_mean=j["frag_mean"], frag_sd=j["frag_sd"],
+                    matepair=j["matepair"], ins_prob1=j["ins_prob1"], del_prob1=j["del_prob1"],
+                    ins_prob2=j["ins_prob2"], del_prob2=j["del_prob2"], frag_len_min=j["frag_len_min"],
+                    frag_len_max=j["frag_len_max"], haplotype_probs=hap_probs, barcodes=barcodes or None,
+                    prob_dup=j["prob_dup"], n_threads=T, read_pool_size=j["read_pool_size"], seed_words=words,
+                    _session=True, **extra)
+    with s:
+        s.generate()
+        sizes, reads = s.sizes()
+        return s.fetch(0), (s.fetch(1) if len(sizes) > 1 else None), reads, s.seed_words_used()
+
+
+def check(ja, O, hs, read_length, n_reads, T, j, hap_probs=None, barcodes=(), seed=1):
+    paired = j["paired"] or j["matepair"]
+    p1 = ja.read_profile(None, None, read_length, 1)
+    p2 = ja.read_profile(None, None, read_length, 2) if paired else None
+    words = ja.seed_words(seed, hs.seed_budget(T))
+    probs = hap_probs if hap_probs is not None else [1.0] * hs.n_haps()
+    o1, o2, used_o = oracle_hap(O, hs, p1, p2, words, n_reads, T, j, probs, list(barcodes))
+    h1, h2, reads, used_h = hip_hap(ja, hs, read_length, words, n_reads, T, j, hap_probs, list(barcodes))
+    assert used_o == used_h
+    if h1 != o1:
+        raise AssertionError("R1 differs at byte %d:\nHIP    %r\noracle %r" % first_diff(h1, o1))
+    if paired and h2 != o2:
+        raise AssertionError("R2 differs at byte %d:\nHIP    %r\noracle %r" % first_diff(h2, o2))
+    return h1, h2
+
+
+def test_reference_like_fixture(ja, O):
+    """tests/testthat/test-sequencer.R:172-272: 5 chromosomes of 100 bp, 4 haplotypes, SE and PE 100 bp."""
+    ref = ja.synthetic_genome([100] * 5, seed=21)
+    hs = random_haplotypes(ref, 4, seed=22, sub_rate=0.1, ins_rate=0.0, del_rate=0.0)
+    h1, _ = check(ja, O, hs, 100, 100, 1, job(paired=False))
+    recs = fastq_records(h1)
+    assert len(recs) == 100 and all(r[0].startswith(b"@hap") and r[2] == b"+" for r in recs)
+    check(ja, O, hs, 100, 100, 1, job(paired=True))
+
+
+@pytest.mark.parametrize("T", [1, 5, 64, 777])
+def test_haplotypes_with_indels(ja, O, T):
+    ref = ja.synthetic_genome([40_000, 9_000, 700], seed=23)
+    hs = random_haplotypes(ref, 4, seed=24, sub_rate=0.01, ins_rate=0.004, del_rate=0.004)
+    check(ja, O, hs, 150, 6000, T, job(), seed=T)
+
+
+def test_dense_mutations_long_indels(ja, O):
+    """Reads that cross many segments: mutation every ~8 bases, indels up to tens of bases."""
+    ref = ja.synthetic_genome([20_000, 3_000], seed=25)
+    hs = random_haplotypes(ref, 3, seed=26, sub_rate=0.06, ins_rate=0.03, del_rate=0.03, mean_indel=12.0)
+    check(ja, O, hs, 150, 4000, 24, job())
+    check(ja, O, hs, 150, 2001, 7, job(paired=False, prob_dup=0.5))
+    check(ja, O, hs, 150, 2000, 9, job(matepair=True, frag_mean=800.0, frag_sd=100.0))
+
+
+def test_unequal_probs_barcodes_and_unmutated_cells(ja, O):
+    ref = ja.synthetic_genome([30_000, 5_000], seed=27)
+    hs = random_haplotypes(ref, 4, seed=28)
+    hs.cells[2][0] = {"chrom_size": 30_000, "old_pos": [], "new_pos": [], "nucleos": []}      # identical to the reference
+    check(ja, O, hs, 150, 5000, 33, job(), hap_probs=[0.5, 0.0, 2.0, 1.0], barcodes=["ACGT", "", "TTGACC", "G"])
+    check(ja, O, hs, 150, 5000, 3, job(ins_prob1=0.05, del_prob1=0.05, ins_prob2=0.02, del_prob2=0.08),
+          hap_probs=[0.0, 0.0, 0.0, 1.0])
+
+
+def test_lane_shards_and_batches(ja, O):
+    ref = ja.synthetic_genome([60_000], seed=29)
+    hs = random_haplotypes(ref, 2, seed=30, sub_rate=0.01, ins_rate=0.003, del_rate=0.003)
+    T, n, j = 80, 6000, job()
+    words = ja.seed_words(5, hs.seed_budget(T))
+    w1, w2, _, _ = hip_hap(ja, hs, 150, words, n, T, j, None, [])
+    parts = [hip_hap(ja, hs, 150, words, n, T, j, None, [], lane_begin=lo, lane_end=hi)[:2]
+             for lo, hi in [(0, 17), (17, 64), (64, 80)]]
+    assert b"".join(p[0] for p in parts) == w1 and b"".join(p[1] for p in parts) == w2
+    b1, b2, _, _ = hip_hap(ja, hs, 150, words, n, T, j, None, [], max_batch_bytes=300_000)
+    assert b1 == w1 and b2 == w2
+
+
+def test_sep_files(ja, O, tmp_path):
+    """write_reads_cpp_sep_files_ (src/hts.h:512-552): reads per haplotype from one reads_per_group draw,
+    then one run per haplotype with one-hot probabilities, files <prefix>_<hap>_R{1,2}.fq."""
+    ref = ja.synthetic_genome([25_000, 4_000], seed=31)
+    hs = random_haplotypes(ref, 3, seed=32, sub_rate=0.01, ins_rate=0.002, del_rate=0.002)
+    T, n = 6, 3000
+    words = ja.seed_words(9, hs.seed_budget(T))
+    prefix = str(tmp_path / "sep")
+    ja.illumina(hs, prefix, n, 150, True, n_threads=T, seed_words=words, sep_files=True, haplotype_probs=[1, 2, 1])
+    p1, p2 = ja.read_profile(None, None, 150, 1), ja.read_profile(None, None, 150, 2)
+    probs = np.array([1.0, 2.0, 1.0])
+    per_file, used = np.zeros(3, dtype=np.uint64), C.c_uint64()
+    assert O.lib().orc_reads_per_group(C.c_uint64(n // 2), probs.ctypes.data_as(C.c_void_p), C.c_uint64(3),
+                                       words.ctypes.data_as(C.c_void_p), C.c_uint64(words.size),
+                                       per_file.ctypes.data_as(C.c_void_p), C.byref(used)) == 0
+    pos = int(used.value)
+    total = 0
+    for h in range(3):
+        one_hot = [1.0 if k == h else 0.0 for k in range(3)]
+        o1, o2, u = oracle_hap(O, hs, p1, p2, words[pos:], int(per_file[h]) * 2, T, job(), one_hot, [])
+        pos += u
+        assert open("%s_hap%d_R1.fq" % (prefix, h), "rb").read() == o1
+        assert open("%s_hap%d_R2.fq" % (prefix, h), "rb").read() == o2
+        total += len(fastq_records(o1))
+    assert total == n // 2
+
+
+def test_bad_tables_are_rejected(ja):
+    ref = ja.synthetic_genome([1000], seed=33)
+    bad = HapSet(ref, [[{"chrom_size": 1000, "old_pos": [10, 5], "new_pos": [10, 5], "nucleos": ["A", "C"]}]])
+    with pytest.raises(ja.JackalopeHipError, match="increasing"):
+        ja.illumina(bad, None, 10, 150, True, n_threads=1, seed_words=ja.seed_words(1, 256), _session=True)
