@@ -61,7 +61,8 @@ using namespace jk;
 
 struct jk_session {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // generator kernels
+    hipStream_t cp_stream = nullptr;   // scan + compaction of the previous batch, overlapping the next one
     uint32_t n_ends = 1;
     bool paired = false;
     std::string out_prefix;
@@ -83,7 +84,7 @@ struct jk_session {
     DevBuf d_seeds, d_lane_reads, d_chrom_reads, d_pool_off;
     std::vector<Batch> batches;
     std::vector<uint64_t> batch_pool_off_index;   // index into d_pool_off of each batch's first entry
-    DevBuf d_pool[2], d_out[2], d_lane_bytes[2], d_lane_off[2], d_block_sums, d_base[2], d_lane_made, d_evw, d_err;
+    DevBuf d_pool[2][2] /* [ping-pong][end] */, d_out[2], d_lane_bytes[2], d_lane_off[2], d_block_sums, d_base[2], d_lane_made, d_evw, d_err;
     uint64_t out_cap = 0;
     IlluminaKernelParams kp{};                    // template, per-batch fields filled at launch
     // results of the last generate()
@@ -93,11 +94,15 @@ struct jk_session {
     bool generated = false;
     uint64_t seed_words_used = 0;
     const volatile int32_t* abort_flag = nullptr;
-    std::vector<hipEvent_t> events;
+    std::vector<hipEvent_t> events;       // [0] start, [1+2b] / [2+2b] around generator b, last = end
+    std::vector<hipEvent_t> gen_done, cp_done;   // per batch, for the two-stream hand-off
 
     ~jk_session() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        for (hipEvent_t e : gen_done) (void)hipEventDestroy(e);
+        for (hipEvent_t e : cp_done) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
+        if (cp_stream) (void)hipStreamDestroy(cp_stream);
     }
 };
 
@@ -142,6 +147,7 @@ static void setup_model(jk_session& s, const jk_illumina_args& a) {
     s.device = a.device;
     JK_HIP(hipSetDevice(s.device));
     JK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    JK_HIP(hipStreamCreateWithFlags(&s.cp_stream, hipStreamNonBlocking));
 
     s.tables = build_illumina_tables(a);
     const uint32_t L = s.tables.read_length;
@@ -208,8 +214,12 @@ static std::vector<uint32_t> take_lane_seeds(jk_session& s, SeedReader& seeds) {
 static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const std::vector<uint64_t>& lane_reads,
                                  uint64_t rec_max, const std::vector<uint32_t>& lane_seeds,
                                  const std::vector<uint32_t>& quotas) {
+    // A batch is one generator launch.  Default: 2^18 lanes = one 1024-thread workgroup on each of the
+    // 256 CUs, so every launch is a single full wave of workgroups and the pool compaction of batch b
+    // (HBM-bound, second stream) runs under the generator of batch b+1 (ALU-bound).
     const uint64_t max_batch = a.max_batch_bytes ? a.max_batch_bytes : (8ULL << 30);
-    const uint64_t max_batch_lanes = 1ULL << 22;
+    uint64_t max_batch_lanes = 1ULL << 18;
+    if (const char* e = std::getenv("JK_BATCH_LANES")) { const long long v = std::atoll(e); if (v >= 64) max_batch_lanes = (uint64_t)v / 64 * 64; }
     std::vector<uint64_t> pool_off;    // concatenation over batches of (n_tiles+1) relative offsets
     uint64_t out_cap = 0, max_pool = 0;
     uint32_t max_lanes = 0;
@@ -244,7 +254,8 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     s.d_quals.upload(s.tables.quals);
     s.d_mm.upload(s.tables.mm_thresh);
     for (uint32_t e = 0; e < s.n_ends; e++) {
-        s.d_pool[e].alloc(max_pool + 64);
+        s.d_pool[0][e].alloc(max_pool + 64);
+        if (s.batches.size() > 1) s.d_pool[1][e].alloc(max_pool + 64);
         s.d_out[e].alloc(out_cap + 64);
         s.d_lane_bytes[e].alloc(s.n_shard * 8);
         s.d_lane_off[e].alloc(s.n_shard * 8);
@@ -252,6 +263,10 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     }
     s.d_lane_made.alloc(s.n_shard * 8);
     s.d_block_sums.alloc((max_lanes / SCAN_BLOCK + 2) * 8);
+    s.gen_done.resize(s.batches.size());
+    s.cp_done.resize(s.batches.size());
+    for (hipEvent_t& e : s.gen_done) JK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : s.cp_done) JK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     s.d_evw.alloc((size_t)s.n_ends * 4 * s.ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
     s.d_err.alloc(4);
 
@@ -491,25 +506,28 @@ static void launch_generate(jk_session& s) {
     for (uint32_t e = 0; e < s.n_ends; e++) JK_HIP(hipMemsetAsync(s.d_base[e].p, 0, 8, s.stream));
     size_t ev = 0;
     JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+    JK_HIP(hipStreamWaitEvent(s.cp_stream, s.events[0], 0));
     for (size_t b = 0; b < s.batches.size(); b++) {
         if (s.abort_flag && *s.abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
         const Batch& B = s.batches[b];
+        const int pp = (int)(b & 1);       // ping-pong pool set
         IlluminaKernelParams P = s.kp;
         P.n_lanes = B.n_lanes;
         P.seeds = s.d_seeds.as<uint32_t>() + B.lane0 * 8;
         P.lane_reads = s.d_lane_reads.as<uint64_t>() + B.lane0;
-        // chromosome-major layout over the whole shard: row stride = n_shard.  The kernel indexes
-        // chrom_reads[ci * n_lanes + lane], so give it a per-batch view only when the batch is the shard.
+        // quotas are laid out [chromosome or cell][lane of the shard]: row stride n_shard
         P.chrom_reads = s.d_chrom_reads.as<uint32_t>() + B.lane0;
         P.pool_off = s.d_pool_off.as<uint64_t>() + s.batch_pool_off_index[b];
         for (uint32_t e = 0; e < 2; e++) {
-            P.pool[e] = e < s.n_ends ? s.d_pool[e].as<uint8_t>() : nullptr;
+            P.pool[e] = e < s.n_ends ? s.d_pool[pp][e].as<uint8_t>() : nullptr;
             P.lane_bytes[e] = e < s.n_ends ? s.d_lane_bytes[e].as<uint64_t>() + B.lane0 : nullptr;
         }
         P.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
         P.chrom_stride = (uint32_t)s.n_shard;
         const uint32_t block = 1024;
         const uint32_t grid = (B.n_lanes + block - 1) / block;
+        // the pool set is free again once the compaction of batch b-2 has read it
+        if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));
         JK_HIP(hipEventRecord(s.events[ev++], s.stream));
 #define JK_LAUNCH(LDS, NE, HAP, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, 1024, HAP>), dim3(grid), dim3(block), SH, s.stream, P)
         if (s.lds_tables) {
@@ -522,22 +540,27 @@ static void launch_generate(jk_session& s) {
 #undef JK_LAUNCH
         JK_HIP(hipGetLastError());
         JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+        JK_HIP(hipEventRecord(s.gen_done[b], s.stream));
+        JK_HIP(hipStreamWaitEvent(s.cp_stream, s.gen_done[b], 0));
         const uint32_t nb = (B.n_lanes + SCAN_BLOCK - 1) / SCAN_BLOCK;
         for (uint32_t e = 0; e < s.n_ends; e++) {
             uint64_t* lb = s.d_lane_bytes[e].as<uint64_t>() + B.lane0;
             uint64_t* lo = s.d_lane_off[e].as<uint64_t>() + B.lane0;
             uint64_t* bs = s.d_block_sums.as<uint64_t>();
             uint64_t* base = s.d_base[e].as<uint64_t>() + b;
-            hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s.stream, lb, lo, bs, B.n_lanes);
-            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.stream, bs, nb, base);
-            hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s.stream, lo, bs, B.n_lanes);
-            hipLaunchKernelGGL(compact_pools_kernel, dim3((B.n_lanes + 63) / 64), dim3(256), 0, s.stream,
-                               s.d_pool[e].as<uint8_t>(), P.pool_off, lb, lo, s.d_out[e].as<uint8_t>(), base, B.n_lanes);
+            hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s.cp_stream, lb, lo, bs, B.n_lanes);
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.cp_stream, bs, nb, base);
+            hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s.cp_stream, lo, bs, B.n_lanes);
+            hipLaunchKernelGGL(compact_pools_kernel, dim3((B.n_lanes + 63) / 64), dim3(256), 0, s.cp_stream,
+                               s.d_pool[pp][e].as<uint8_t>(), P.pool_off, lb, lo, s.d_out[e].as<uint8_t>(), base, B.n_lanes);
             JK_HIP(hipGetLastError());
         }
+        JK_HIP(hipEventRecord(s.cp_done[b], s.cp_stream));
     }
+    if (!s.batches.empty()) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[s.batches.size() - 1], 0));
     JK_HIP(hipEventRecord(s.events[ev++], s.stream));
     JK_HIP(hipStreamSynchronize(s.stream));
+    JK_HIP(hipStreamSynchronize(s.cp_stream));
 
     uint32_t err = 0;
     JK_HIP(hipMemcpy(&err, s.d_err.p, 4, hipMemcpyDeviceToHost));
