@@ -101,34 +101,45 @@ struct IlluminaKernelParams {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Byte appender into a lane's pool (one column of its tile).  Bytes are gathered into a 32-bit word
-// and stored when the word is complete.  A stream that starts mid-word stores that first word with
-// zeros in the bytes below its start: those bytes belong to the stream that ends there, which
-// writes them LATER in program order and byte by byte (os_flush), so nothing is lost.
+// Byte appender into a lane's pool (one column of its tile).  Bytes are gathered in a 64-bit
+// shift register and leave as whole 32-bit words.  In the per-base loop every lane appends one byte
+// per iteration, so after every 4th iteration each lane has a full word whatever its phase: the
+// store is then issued wave-uniformly (no exec masking, one store instruction per 4 bases instead
+// of one per base; first PMC pass of v3: SQ_INSTS_VMEM_WR was 600 per pair for 165 words).
+// A stream that starts mid-word stores that first word with zeros in the bytes below its start:
+// those bytes belong to the stream that ends there, which writes them LATER in program order,
+// byte by byte (os_flush), so nothing is lost.
 // ---------------------------------------------------------------------------------------------
 struct OutStream {
     uint8_t* wp;       // address of the current word (this lane's column of the tile)
-    uint32_t pos;      // byte offset in the lane's stream
-    uint32_t w;        // bytes gathered for the current word
+    uint64_t acc;      // pending bytes, oldest in the low byte
+    uint32_t cnt;      // number of pending bytes (0..7)
+    uint32_t pos;      // byte offset in the lane's stream of the next byte to append
 };
 
 constexpr uint32_t TILE_ROW = 64 * 4;      // bytes between consecutive words of one lane
 
 __device__ __forceinline__ void os_begin(OutStream& s, uint8_t* lane_base, uint32_t pos) {
     s.wp = lane_base + (size_t)(pos >> 2) * TILE_ROW;
-    s.pos = pos; s.w = 0;
+    s.pos = pos; s.acc = 0; s.cnt = pos & 3u;
+}
+__device__ __forceinline__ void os_store_word(OutStream& s) {      // requires cnt >= 4
+    *reinterpret_cast<uint32_t*>(s.wp) = (uint32_t)s.acc;
+    s.acc >>= 32; s.cnt -= 4u; s.wp += TILE_ROW;
+}
+__device__ __forceinline__ void os_put_raw(OutStream& s, uint32_t byte) {   // caller stores words and tracks pos
+    s.acc |= (uint64_t)byte << (8u * s.cnt);
+    s.cnt++;
 }
 __device__ __forceinline__ void os_put(OutStream& s, uint32_t byte) {
-    const uint32_t k = s.pos & 3u;
-    s.w |= byte << (8u * k);
+    os_put_raw(s, byte);
     s.pos++;
-    if (k == 3u) { *reinterpret_cast<uint32_t*>(s.wp) = s.w; s.w = 0; s.wp += TILE_ROW; }
+    if (s.cnt >= 4u) os_store_word(s);
 }
 // write the pending bytes of the current word one by one; the stream is abandoned afterwards
 __device__ __forceinline__ void os_flush(OutStream& s) {
-    const uint32_t k = s.pos & 3u;
-    for (uint32_t j = 0; j < k; j++) s.wp[j] = (uint8_t)(s.w >> (8u * j));
-    s.w = 0;
+    for (uint32_t j = 0; j < s.cnt; j++) s.wp[j] = (uint8_t)(s.acc >> (8u * j));
+    s.acc = 0; s.cnt = 0;
 }
 
 struct LaneRng {
@@ -502,11 +513,15 @@ illumina_kernel(IlluminaKernelParams P) {
                     q = jk_n_qual(rng());
                     ch = 'N';
                 }
-                os_put(o, ch);
-                os_put(oq, q);
+                os_put_raw(o, ch);
+                os_put_raw(oq, q);
+                if ((op & 3u) == 3u) { os_store_word(o); os_store_word(oq); }    // wave-uniform: every lane has >= 4 bytes
             }
+            o.pos += n_out; oq.pos += n_out;
+            if (o.cnt >= 4u) os_store_word(o);
+            if (oq.cnt >= 4u) os_store_word(oq);
             os_put(oq, '\n');
-            os_flush(o);
+            os_flush(o);               // after every word store of oq above (see OutStream)
             o = oq;                    // the next record continues where the quality stream stopped
             reverse = !reverse;
         }
