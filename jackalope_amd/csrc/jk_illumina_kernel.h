@@ -166,7 +166,7 @@ __device__ __forceinline__ uint32_t base_char(uint32_t code) { return (0x4741435
 
 // tables either in LDS or global
 struct TabPtrs {
-    const uint4* info4; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm;
+    const uint32_t* info; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm;
 };
 
 struct HapSeg { uint64_t addr, begin, end; };   // haplotype positions [begin, end) lie contiguously at seq[addr + (pos - hpos)]
@@ -225,9 +225,9 @@ illumina_kernel(IlluminaKernelParams P) {
         for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_mm[i] = P.mm_thresh[i];
         for (uint32_t i = threadIdx.x; i < P.n_info; i += blockDim.x) s_info[i] = P.info[i];
         __syncthreads();
-        T.info4 = reinterpret_cast<const uint4*>(s_info); T.thresh = s_thresh; T.quals = s_quals; T.mm = s_mm;
+        T.info = s_info; T.thresh = s_thresh; T.quals = s_quals; T.mm = s_mm;
     } else {
-        T.info4 = reinterpret_cast<const uint4*>(P.info); T.thresh = P.thresh; T.quals = P.quals; T.mm = P.mm_thresh;
+        T.info = P.info; T.thresh = P.thresh; T.quals = P.quals; T.mm = P.mm_thresh;
     }
 
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -464,8 +464,12 @@ illumina_kernel(IlluminaKernelParams P) {
             uint32_t nes = bc ? 0u : next_slow(0);
             bool pending = false; uint32_t pend_base = 0;
             const uint32_t info_base = i * L;
+            // the 4 bytes of a quad of bases / qualities are gathered with wave-uniform shifts and merged
+            // into the streams' accumulators once per quad (the lane's phase o.cnt / oq.cnt is < 4 and
+            // does not change inside the loop)
+            uint32_t grp_b = 0, grp_q = 0;
+            const uint32_t sh_b = 8u * o.cnt, sh_q = 8u * oq.cnt;
             for (uint32_t op = 0; op < n_out; op++) {
-                const uint4 inf4 = T.info4[info_base + op];
                 uint32_t c;
                 if (pp < nes) {                 // fast path: next reference base
                     c = src_next();
@@ -493,7 +497,7 @@ illumina_kernel(IlluminaKernelParams P) {
                 }
                 uint32_t q, ch;
                 if (c < 4u) {
-                    const uint32_t inf = c == 0 ? inf4.x : c == 1 ? inf4.y : c == 2 ? inf4.z : inf4.w;
+                    const uint32_t inf = T.info[(info_base + op) * 4u + c];
                     const uint64_t x1 = rng();
                     const uint32_t e = (inf & 0xffffffu) + runif_index32(x1, inf >> 24);
                     const uint64_t th = T.thresh[e];
@@ -513,10 +517,16 @@ illumina_kernel(IlluminaKernelParams P) {
                     q = jk_n_qual(rng());
                     ch = 'N';
                 }
-                os_put_raw(o, ch);
-                os_put_raw(oq, q);
-                if ((op & 3u) == 3u) { os_store_word(o); os_store_word(oq); }    // wave-uniform: every lane has >= 4 bytes
+                const uint32_t bsh = 8u * (op & 3u);       // wave-uniform
+                grp_b |= ch << bsh;
+                grp_q |= q << bsh;
+                if ((op & 3u) == 3u) {                     // wave-uniform: every lane stores one word per stream
+                    o.acc |= (uint64_t)grp_b << sh_b; o.cnt += 4u; os_store_word(o); grp_b = 0;
+                    oq.acc |= (uint64_t)grp_q << sh_q; oq.cnt += 4u; os_store_word(oq); grp_q = 0;
+                }
             }
+            o.acc |= (uint64_t)grp_b << sh_b; o.cnt += n_out & 3u;
+            oq.acc |= (uint64_t)grp_q << sh_q; oq.cnt += n_out & 3u;
             o.pos += n_out; oq.pos += n_out;
             if (o.cnt >= 4u) os_store_word(o);
             if (oq.cnt >= 4u) os_store_word(oq);
