@@ -35,15 +35,31 @@ def cpu_baseline(genome, prof1, prof2, read_length, sample_pairs, cores):
     lanes = max(cores * 8, 8)
     words = ja.seed_words(12345, 16 * lanes)
     t0 = time.perf_counter()
-    r1, r2, _ = O.illumina_ref(genome, paired=True, n_reads=2 * sample_pairs, prob_dup=0.02, n_threads=lanes,
-                               read_pool_size=1000, shape=16.0, scale=25.0, fmin=read_length, fmax=2 ** 32 - 1,
-                               prof1=prof1, prof2=prof2, ins1=0.00009, del1=0.00011, ins2=0.00015, del2=0.00023,
-                               words=words)
+    tb = {}
+    O.illumina_ref(genome, paired=True, n_reads=2 * sample_pairs, prob_dup=0.02, n_threads=lanes,
+                   read_pool_size=1000, shape=16.0, scale=25.0, fmin=read_length, fmax=2 ** 32 - 1,
+                   prof1=prof1, prof2=prof2, ins1=0.00009, del1=0.00011, ins2=0.00015, del2=0.00023,
+                   words=words, discard=True, thread_bytes=tb)
     dt = time.perf_counter() - t0
-    pairs = r1.count(b"\n") // 4
+    pairs = sample_pairs
     return {"value": round(pairs / dt / 1e6, 6), "unit": "M paired reads/sec", "cores": cores, "kind": "port",
-            "sample": "%d pairs of the same 100 Mbp PE150 workload on %d lanes, oracle/jk_oracle.cpp with OpenMP, "
-                      "FASTQ kept in memory (%.1f s)" % (pairs, lanes, dt)}
+            "sample": "%d pairs of the same 100 Mbp PE150 workload on %d lanes, oracle/jk_oracle.cpp (CPU restatement "
+                      "of the reference path) with OpenMP on %d threads, null sink: %d FASTQ bytes formatted and "
+                      "dropped (%.1f s)" % (pairs, lanes, cores, int(tb[0].sum() + tb[1].sum()), dt)}
+
+
+def pmc_traffic(pairs_per_launch):
+    """HBM bytes per generator launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    collected in separate passes, KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950), if they were taken at this launch size."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_generator.json")
+    try:
+        d = json.load(open(path))
+        if abs(d["pairs_per_launch"] - pairs_per_launch) > 0.01 * pairs_per_launch:
+            return None
+        return int((2.0 * d["fetch_size_kb"] + d["write_size_kb"]) * 1024)
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -74,14 +90,16 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import jackalope_amd as ja
+    from jackalope_amd.sharding import lane_block, exchange_counts
 
     read_length = 150
     genome = ja.synthetic_genome([int(a.genome_mbp * 1e6)], seed=2)
     total_lanes = a.lanes * world
     n_reads = 2 * a.pairs * world
     words = ja.seed_words(12345, 16 * total_lanes)
+    lane_lo, lane_hi = lane_block(rank, world, total_lanes)
     sess = ja.illumina(genome, None, n_reads, read_length, True, n_threads=total_lanes, seed_words=words,
-                       device=local_rank, lane_begin=rank * a.lanes, lane_end=(rank + 1) * a.lanes, _session=True)
+                       device=local_rank, lane_begin=lane_lo, lane_end=lane_hi, _session=True)
 
     def sync():
         torch.cuda.synchronize()
@@ -107,25 +125,24 @@ def main():
     pairs_rank = reads_made // 2
     fastq_bytes = sum(sizes)
 
-    # count exchange over RCCL: per-rank {pairs, bytes R1, bytes R2}; max over ranks of the time
-    stats = torch.tensor([pairs_rank, sizes[0], sizes[1]], dtype=torch.int64, device="cuda")
+    # the path's only exchange: per-rank {reads, bytes R1, bytes R2} all-gathered over RCCL -> file offsets
+    # and totals; then the max over ranks of the timed region
+    offsets, (total_reads, total_bytes) = exchange_counts(reads_made, sizes, device="cuda")
+    total_pairs = total_reads // 2
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
-        gathered = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        total_pairs = int(sum(int(g[0]) for g in gathered))
-    else:
-        total_pairs = pairs_rank
     elapsed = float(tmax.item())
 
     if rank == 0:
         value = total_pairs * a.steps / elapsed / 1e6
         # roofline of the dominant kernel (the generator): algorithmic bytes per launch = FASTQ bytes it
         # emits + 300 reference bytes per pair, over its average HIP-event duration
-        alg_bytes = fastq_bytes + 300 * pairs_rank
-        kern_s = gen_ms / a.steps / 1e3
+        n_launch = max(sess.n_batches(), 1)
+        alg_bytes = (fastq_bytes + 300 * pairs_rank) / n_launch          # per launch
+        kern_s = gen_ms / a.steps / 1e3 / n_launch                       # average launch duration
         achieved = alg_bytes / kern_s / 1e9
+        traffic = pmc_traffic(pairs_rank / n_launch)
         out = {
             "metric": "M paired reads/sec (PE150, 30x of 100 Mbp)", "value": round(value, 3),
             "unit": "M paired reads/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -136,16 +153,21 @@ def main():
                        "pairs_per_gpu": a.pairs, "lanes_per_gpu": a.lanes, "read_length": read_length,
                        "parallelism": "lanes sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "illumina_ref_kernel", "kernel_ms": round(gen_ms / a.steps, 3),
-                         "algorithmic_bytes_per_pair": round(alg_bytes / max(pairs_rank, 1), 2),
-                         "note": "integer-ALU bound: ~1200 pcg64 steps (128-bit multiply) per pair; "
-                                 "draws/s = %.3g" % (1206.0 * pairs_rank / kern_s)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "illumina_kernel<LDS,2,1024,ref>", "launches_per_step": n_launch,
+                         "kernel_ms": round(kern_s * 1e3, 3),
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "algorithmic_bytes_per_pair": round(alg_bytes * n_launch / max(pairs_rank, 1), 2),
+                         "note": "integer-ALU bound: ~1206 pcg64 steps (128-bit multiply) per pair, "
+                                 "%.3g draws/s against a measured pure-pcg ceiling of 1.38e12 draws/s/GPU; "
+                                 "traffic = (2*FETCH_SIZE + WRITE_SIZE) of the committed rocprofv3 --pmc passes "
+                                 "(profiles/), null when they were taken at another launch size"
+                                 % (1206.0 * pairs_rank / n_launch / kern_s)},
             "device_ms_per_step": round(all_ms / a.steps, 3),
         }
         if not a.no_cpu_baseline:
             cores = min(os.cpu_count() or 1, 64)
-            sample = a.cpu_sample_pairs or 50_000 * min(cores, 16)
+            sample = a.cpu_sample_pairs or min(200_000 * cores, 12_000_000)     # about 15-20 s of CPU work
             p1, p2 = ja.read_profile(None, None, read_length, 1), ja.read_profile(None, None, read_length, 2)
             out["cpu_baseline"] = cpu_baseline(genome, p1, p2, read_length, sample, cores)
         print(json.dumps(out))

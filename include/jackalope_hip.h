@@ -153,6 +153,8 @@ int jk_session_write(const jk_session* s);
 /* Timing of the last generate(): HIP-event milliseconds on the session's stream.
  * ms[0] generator kernel(s), ms[1] scan + compaction kernels, ms[2] whole generate() (device). */
 int jk_session_timing(const jk_session* s, double ms[3]);
+/* Number of generator launches (batches of lanes) one generate() makes. */
+uint32_t jk_session_batches(const jk_session* s);
 /* Number of sub-seed words consumed while opening the session. */
 uint64_t jk_session_seed_words_used(const jk_session* s);
 /* Per-lane counts, for the multi-GPU count/offset exchange: n = lane_end - lane_begin entries. */

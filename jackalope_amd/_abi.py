@@ -86,7 +86,7 @@ EXPORTS = [
     "jk_last_error", "jk_version", "jk_illumina_ref", "jk_illumina_hap",
     "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_session_generate", "jk_session_sizes",
     "jk_session_device_ptr", "jk_session_fetch", "jk_session_write", "jk_session_timing",
-    "jk_session_seed_words_used", "jk_session_lane_bytes", "jk_session_close",
+    "jk_session_seed_words_used", "jk_session_batches", "jk_session_lane_bytes", "jk_session_close",
     "jk_split_int", "jk_reads_per_group", "jk_alias_build", "jk_hap_chrom_full",
     "jk_host_eval", "jk_dev_eval", "jk_eval_set_gamma",
 ]
@@ -114,6 +114,8 @@ def lib():
     L.jk_version.restype = C.c_char_p
     L.jk_session_seed_words_used.restype = C.c_uint64
     L.jk_session_seed_words_used.argtypes = [C.c_void_p]
+    L.jk_session_batches.restype = C.c_uint32
+    L.jk_session_batches.argtypes = [C.c_void_p]
     L.jk_illumina_ref.argtypes = [C.POINTER(RefGenomeView), C.POINTER(IlluminaArgs)]
     L.jk_illumina_hap.argtypes = [C.POINTER(HapSetView), C.POINTER(IlluminaArgs)]
     L.jk_illumina_ref_open.argtypes = [C.POINTER(RefGenomeView), C.POINTER(IlluminaArgs), C.POINTER(C.c_void_p)]

@@ -740,6 +740,7 @@ int jk_session_timing(const jk_session* s, double ms[3]) {
 }
 
 uint64_t jk_session_seed_words_used(const jk_session* s) { return s ? s->seed_words_used : 0; }
+uint32_t jk_session_batches(const jk_session* s) { return s ? (uint32_t)s->batches.size() : 0; }
 
 int jk_session_lane_bytes(const jk_session* s, uint32_t end, uint64_t* out, uint64_t n) {
     return guarded([&] {

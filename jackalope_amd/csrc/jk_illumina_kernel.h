@@ -635,7 +635,7 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
 // ---------------------------------------------------------------------------------------------
 // Exclusive scan of per-lane byte counts (u64), three small kernels.
 // ---------------------------------------------------------------------------------------------
-constexpr int SCAN_BLOCK = 1024;
+constexpr int SCAN_BLOCK = 256;     // small blocks co-reside with the generator (which fills 16 of 32 wave slots per CU)
 
 __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t* total) {
     __shared__ uint64_t wsum[SCAN_BLOCK / 64];

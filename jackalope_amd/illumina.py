@@ -119,6 +119,9 @@ class IlluminaSession:
         _abi.check(_abi.lib().jk_session_timing(self._h, ms))
         return {"generate_kernel": ms[0], "scan_compact": ms[1], "total": ms[2]}
 
+    def n_batches(self):
+        return int(_abi.lib().jk_session_batches(self._h))
+
     def seed_words_used(self):
         return int(_abi.lib().jk_session_seed_words_used(self._h))
 
