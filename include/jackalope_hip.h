@@ -11,6 +11,8 @@
  *   --------------------------------------------------  -----------------------------------------
  *   illumina_ref_cpp   src/hts_illumina.cpp:589-649     jk_illumina_ref
  *   illumina_hap_cpp   src/hts_illumina.cpp:662-739     jk_illumina_hap
+ *   pacbio_ref_cpp     src/hts_pacbio.cpp:579-640       jk_pacbio_ref
+ *   pacbio_hap_cpp     src/hts_pacbio.cpp:646-715       jk_pacbio_hap
  *   write_reads_cpp_ / write_reads_one_filetype_        jk_session_* (plan, generate, fetch, write)
  *                      src/hts.h:323-500
  *   mt_seeds / seeded_pcg (R RNG contract)              jk_seed_source
@@ -126,12 +128,44 @@ typedef struct jk_illumina_args {
     uint64_t max_batch_bytes;         /* cap on device memory for one batch's read pools; 0 = default */
 } jk_illumina_args;
 
+/* Arguments of pacbio_ref_cpp / pacbio_hap_cpp, same names and meaning (src/hts_pacbio.cpp:579-602, :646-671). */
+typedef struct jk_pacbio_args {
+    const char* out_prefix;           /* file <prefix>_R1.fq */
+    int32_t sep_files;                /* hap only */
+    int32_t compress;                 /* only 0 is implemented */
+    const char* comp_method;
+    uint64_t n_reads;
+    uint64_t n_threads;               /* number of lanes */
+    int32_t show_progress;
+    uint64_t read_pool_size;
+    double prob_dup;
+    double scale, sigma, loc;         /* lognormal read lengths (used when n_read_lens == 0) */
+    double min_read_len;
+    const double* read_probs;         /* custom read lengths: sampling weights, [n_read_lens] */
+    const uint64_t* read_lens;        /*                      lengths */
+    uint64_t n_read_lens;
+    uint64_t max_passes;
+    const double* chi2_params_n;      /* [3] */
+    const double* chi2_params_s;      /* [5] */
+    const double* sqrt_params;        /* [2] */
+    const double* norm_params;        /* [2] */
+    double prob_thresh, prob_ins, prob_del, prob_subst;
+    const double* haplotype_probs;    /* hap only, [n_haps]; NULL = all 1 */
+    jk_seed_source seeds;
+    const volatile int32_t* abort_flag;
+    uint64_t lane_begin, lane_end;
+    int32_t device;
+    uint64_t max_batch_bytes;
+} jk_pacbio_args;
+
 const char* jk_last_error(void);
 const char* jk_version(void);
 
 /* One-shot entry points: generate and write the FASTQ files, like the reference's functions. */
 int jk_illumina_ref(const jk_ref_genome* genome, const jk_illumina_args* args);
 int jk_illumina_hap(const jk_hap_set* haps, const jk_illumina_args* args);
+int jk_pacbio_ref(const jk_ref_genome* genome, const jk_pacbio_args* args);
+int jk_pacbio_hap(const jk_hap_set* haps, const jk_pacbio_args* args);
 
 /* Session API (what the one-shot calls are made of; used by tests and bench.py so that the
  * generated FASTQ can stay resident in HBM). */
@@ -139,6 +173,8 @@ typedef struct jk_session jk_session;
 
 int jk_illumina_ref_open(const jk_ref_genome* genome, const jk_illumina_args* args, jk_session** out);
 int jk_illumina_hap_open(const jk_hap_set* haps, const jk_illumina_args* args, jk_session** out);
+int jk_pacbio_ref_open(const jk_ref_genome* genome, const jk_pacbio_args* args, jk_session** out);
+int jk_pacbio_hap_open(const jk_hap_set* haps, const jk_pacbio_args* args, jk_session** out);
 /* Run every batch of this session's lanes: generator kernel, per-lane byte-count scan, pool
  * compaction into the lane-major FASTQ images.  May be called repeatedly (same output each time). */
 int jk_session_generate(jk_session* s);
@@ -182,11 +218,17 @@ enum {
     JK_OP_FRAG_START = 6,   /* in: x, aux = span         -> (uint64)(u * span)               */
     JK_OP_LOG = 7,          /* in: bits of a double      -> bits of log                      */
     JK_OP_SQRT = 8,         /* in: bits of a double      -> bits of sqrt                     */
-    JK_OP_GAMMA_STREAM = 9  /* in: 8 seed words per stream, out: `aux` gamma(16,25)-style draws (bits); shape/scale via jk_dev_set_gamma */
+    JK_OP_GAMMA_STREAM = 9, /* in: 8 seed words per stream, out: `aux` gamma draws (bits); shape/scale via jk_eval_set_gamma */
+    JK_OP_EXP = 10,         /* in: bits of x            -> bits of exp(x), ~0 if outside the supported range */
+    JK_OP_POW = 11,         /* in: (bits x, bits y)     -> bits of pow(x, y), ~0 if outside the main path */
+    JK_OP_LOG10 = 12,       /* in: bits of x            -> bits of log10(x) */
+    JK_OP_QNORM = 13,       /* in: bits of p            -> bits of qnorm(p, 0, 1) (AS 241) */
+    JK_OP_RUNIF_AB = 14     /* in: (x, bits a, c.m, c.e) -> bits of (double)(a + runif_01 * c), c = b - a in x87 */
 };
 int jk_host_eval(int what, const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out);
 int jk_dev_eval(int device, int what, const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out);
 void jk_eval_set_gamma(double shape, double scale);
+void jk_x87_one_minus(double p, uint64_t* m, int32_t* e);   /* 1 - p in x87 extended precision */
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ JK_OK = 0
 JK_ERR_ARG, JK_ERR_UNSUPPORTED, JK_ERR_DEVICE, JK_ERR_IO, JK_ERR_SEEDS, JK_ERR_ABORTED = 1, 2, 3, 4, 5, 6
 
 (OP_PCG_STREAM, OP_RUNIF_INDEX, OP_RUNIF_DOUBLE, OP_CANONICAL, OP_N_QUAL, OP_LT_HALF, OP_FRAG_START,
- OP_LOG, OP_SQRT, OP_GAMMA_STREAM) = range(10)
+ OP_LOG, OP_SQRT, OP_GAMMA_STREAM, OP_EXP, OP_POW, OP_LOG10, OP_QNORM, OP_RUNIF_AB) = range(15)
 
 
 class JackalopeHipError(RuntimeError):
@@ -81,14 +81,33 @@ class IlluminaArgs(C.Structure):
                 ("max_batch_bytes", C.c_uint64)]
 
 
+class PacbioArgs(C.Structure):
+    _fields_ = [("out_prefix", C.c_char_p), ("sep_files", C.c_int32), ("compress", C.c_int32),
+                ("comp_method", C.c_char_p),
+                ("n_reads", C.c_uint64), ("n_threads", C.c_uint64), ("show_progress", C.c_int32),
+                ("read_pool_size", C.c_uint64), ("prob_dup", C.c_double),
+                ("scale", C.c_double), ("sigma", C.c_double), ("loc", C.c_double), ("min_read_len", C.c_double),
+                ("read_probs", C.POINTER(C.c_double)), ("read_lens", C.POINTER(C.c_uint64)), ("n_read_lens", C.c_uint64),
+                ("max_passes", C.c_uint64),
+                ("chi2_params_n", C.POINTER(C.c_double)), ("chi2_params_s", C.POINTER(C.c_double)),
+                ("sqrt_params", C.POINTER(C.c_double)), ("norm_params", C.POINTER(C.c_double)),
+                ("prob_thresh", C.c_double), ("prob_ins", C.c_double), ("prob_del", C.c_double), ("prob_subst", C.c_double),
+                ("haplotype_probs", C.POINTER(C.c_double)),
+                ("seeds", SeedSource),
+                ("abort_flag", C.POINTER(C.c_int32)),
+                ("lane_begin", C.c_uint64), ("lane_end", C.c_uint64),
+                ("device", C.c_int32),
+                ("max_batch_bytes", C.c_uint64)]
+
+
 # every symbol include/jackalope_hip.h declares
 EXPORTS = [
-    "jk_last_error", "jk_version", "jk_illumina_ref", "jk_illumina_hap",
-    "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_session_generate", "jk_session_sizes",
+    "jk_last_error", "jk_version", "jk_illumina_ref", "jk_illumina_hap", "jk_pacbio_ref", "jk_pacbio_hap",
+    "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_pacbio_ref_open", "jk_pacbio_hap_open", "jk_session_generate", "jk_session_sizes",
     "jk_session_device_ptr", "jk_session_fetch", "jk_session_write", "jk_session_timing",
     "jk_session_seed_words_used", "jk_session_batches", "jk_session_lane_bytes", "jk_session_close",
     "jk_split_int", "jk_reads_per_group", "jk_alias_build", "jk_hap_chrom_full",
-    "jk_host_eval", "jk_dev_eval", "jk_eval_set_gamma",
+    "jk_host_eval", "jk_dev_eval", "jk_eval_set_gamma", "jk_x87_one_minus",
 ]
 
 _lib = None
@@ -120,6 +139,10 @@ def lib():
     L.jk_illumina_hap.argtypes = [C.POINTER(HapSetView), C.POINTER(IlluminaArgs)]
     L.jk_illumina_ref_open.argtypes = [C.POINTER(RefGenomeView), C.POINTER(IlluminaArgs), C.POINTER(C.c_void_p)]
     L.jk_illumina_hap_open.argtypes = [C.POINTER(HapSetView), C.POINTER(IlluminaArgs), C.POINTER(C.c_void_p)]
+    L.jk_pacbio_ref.argtypes = [C.POINTER(RefGenomeView), C.POINTER(PacbioArgs)]
+    L.jk_pacbio_hap.argtypes = [C.POINTER(HapSetView), C.POINTER(PacbioArgs)]
+    L.jk_pacbio_ref_open.argtypes = [C.POINTER(RefGenomeView), C.POINTER(PacbioArgs), C.POINTER(C.c_void_p)]
+    L.jk_pacbio_hap_open.argtypes = [C.POINTER(HapSetView), C.POINTER(PacbioArgs), C.POINTER(C.c_void_p)]
     L.jk_session_generate.argtypes = [C.c_void_p]
     L.jk_session_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.jk_session_device_ptr.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -139,6 +162,8 @@ def lib():
     L.jk_dev_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     L.jk_eval_set_gamma.argtypes = [C.c_double, C.c_double]
     L.jk_eval_set_gamma.restype = None
+    L.jk_x87_one_minus.argtypes = [C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    L.jk_x87_one_minus.restype = None
     _lib = L
     return L
 

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -13,6 +14,9 @@
 #include "../../include/jackalope_hip.h"
 #include "jk_host.h"
 #include "jk_illumina_kernel.h"
+#include "jk_math2.h"
+#include "jk_nmath.h"
+#include "jk_pacbio_kernel.h"
 
 namespace jk {
 
@@ -46,6 +50,8 @@ struct DevBuf {
     }
 };
 
+constexpr int JK_ERR_RETRY = 1000;   // internal: PacBio pools were too small, regenerate with larger ones
+
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 static inline uint32_t n_digits(uint64_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; d++; } return d; }
 
@@ -75,8 +81,13 @@ struct jk_session {
     bool lds_tables = false;
     size_t lds_bytes = 0;
     bool hap = false;
+    bool pacbio = false;
+    PacbioKernelParams kpb{};
+    DevBuf d_len_thresh, d_len_alias, d_lens, d_thr_tab, d_pass_tab, d_ev2;
     uint32_t ev_words = 0;
     uint64_t nuc_base = 0;     // offset of the haplotypes' nucleotide blob inside d_seq
+    double pool_scale = 1.25;  // PacBio: pool capacity relative to the expected bytes (grown on overflow)
+    std::function<void()> replan;   // PacBio: re-plan pools after pool_scale changed
     DevBuf d_cell_off, d_new_pos, d_ref_shift, d_nuc_len, d_nuc_off, d_cell_size, d_bc_blob, d_bc_len;
     // lanes of this shard
     uint64_t n_lanes_total = 0, lane_begin = 0, lane_end = 0, n_shard = 0;
@@ -123,9 +134,14 @@ static void upload_genome(jk_session& s, const jk_ref_genome& g, const char* blo
     for (uint64_t i = 0; i < g.n_chroms; i++)
         if (len[i]) JK_HIP(hipMemcpy(s.d_seq.as<uint8_t>() + off[i], g.chrom_seqs[i], len[i], hipMemcpyHostToDevice));
     // T,C,A,G -> 0..3, everything else -> 4 (what nt_map / cmp_map of the reference distinguish)
-    hipLaunchKernelGGL(encode_bases_kernel, dim3(2048), dim3(256), 0, 0, s.d_seq.as<uint8_t>(), total);
+    DevBuf bad; bad.alloc(4);
+    JK_HIP(hipMemset(bad.p, 0, 4));
+    hipLaunchKernelGGL(encode_bases_kernel, dim3(2048), dim3(256), 0, 0, s.d_seq.as<uint8_t>(), total, bad.as<uint32_t>());
     JK_HIP(hipGetLastError());
     JK_HIP(hipDeviceSynchronize());
+    uint32_t bad_h = 0;
+    JK_HIP(hipMemcpy(&bad_h, bad.p, 4, hipMemcpyDeviceToHost));
+    if (bad_h) throw Error(JK_ERR_UNSUPPORTED, "the genome contains bytes 0x00-0x03, which the GPU path cannot represent");
     s.d_chrom_off.upload(off);
     s.d_chrom_len.upload(len);
     s.n_chroms = (uint32_t)g.n_chroms;
@@ -185,11 +201,11 @@ static void check_barcode(const std::string& bc, uint32_t L) {
 }
 
 // Lanes of the run and of this process's shard; per-lane read quotas (src/hts.h:334-336).
-static std::vector<uint64_t> plan_lanes(jk_session& s, const jk_illumina_args& a, uint64_t n_reads) {
-    uint64_t T = a.n_threads ? a.n_threads : 1;
+static std::vector<uint64_t> plan_lanes(jk_session& s, uint64_t n_threads, uint64_t lane_begin, uint64_t lane_end, uint64_t n_reads) {
+    uint64_t T = n_threads ? n_threads : 1;
     s.n_lanes_total = T;
-    s.lane_begin = a.lane_begin;
-    s.lane_end = a.lane_end ? a.lane_end : T;
+    s.lane_begin = lane_begin;
+    s.lane_end = lane_end ? lane_end : T;
     if (s.lane_begin > s.lane_end || s.lane_end > T) throw Error(JK_ERR_ARG, "lane shard out of range");
     s.n_shard = s.lane_end - s.lane_begin;
     std::vector<uint64_t> per_lane = split_int(n_reads / s.n_ends, T);
@@ -211,16 +227,16 @@ static std::vector<uint32_t> take_lane_seeds(jk_session& s, SeedReader& seeds) {
 
 // Pools: tiles of 64 lanes (one wave), every lane of a tile gets the capacity of the tile's largest
 // quota of maximal records; a batch is a run of whole tiles.  Then all device buffers.
-static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const std::vector<uint64_t>& lane_reads,
-                                 uint64_t rec_max, const std::vector<uint32_t>& lane_seeds,
-                                 const std::vector<uint32_t>& quotas) {
-    // A batch is one generator launch.  Default: 2^18 lanes = one 1024-thread workgroup on each of the
-    // 256 CUs, so every launch is a single full wave of workgroups and the pool compaction of batch b
-    // (HBM-bound, second stream) runs under the generator of batch b+1 (ALU-bound).
-    const uint64_t max_batch = a.max_batch_bytes ? a.max_batch_bytes : (8ULL << 30);
-    uint64_t max_batch_lanes = 1ULL << 18;
+// lane_cap[l] = pool bytes lane l may need.  Plans batches/tiles and allocates everything that does not
+// depend on the sequencer model.  Returns the largest number of lanes in a batch.
+static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint64_t lanes_per_batch,
+                                  const std::vector<uint64_t>& lane_cap, const std::vector<uint64_t>& lane_reads,
+                                  const std::vector<uint32_t>& lane_seeds, const std::vector<uint32_t>& quotas) {
+    s.batches.clear(); s.batch_pool_off_index.clear();
+    const uint64_t max_batch = max_batch_bytes ? max_batch_bytes : (8ULL << 30);
+    uint64_t max_batch_lanes = lanes_per_batch;
     if (const char* e = std::getenv("JK_BATCH_LANES")) { const long long v = std::atoll(e); if (v >= 64) max_batch_lanes = (uint64_t)v / 64 * 64; }
-    std::vector<uint64_t> pool_off;    // concatenation over batches of (n_tiles+1) relative offsets
+    std::vector<uint64_t> pool_off;
     uint64_t out_cap = 0, max_pool = 0;
     uint32_t max_lanes = 0;
     uint64_t l = 0;
@@ -231,9 +247,9 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
         uint64_t used = 0;
         while (l < s.n_shard && b.n_lanes < max_batch_lanes) {
             const uint64_t tl = std::min<uint64_t>(64, s.n_shard - l);
-            uint64_t maxq = 0;
-            for (uint64_t k = 0; k < tl; k++) maxq = std::max(maxq, lane_reads[l + k] / s.n_ends);
-            const uint64_t cap = align_up(maxq * rec_max, 4) * 64;
+            uint64_t mx = 0;
+            for (uint64_t k = 0; k < tl; k++) mx = std::max(mx, lane_cap[l + k]);
+            const uint64_t cap = align_up(mx, 4) * 64;
             if (b.n_lanes > 0 && used + cap > max_batch) break;
             used += cap; pool_off.push_back(used); b.n_lanes += (uint32_t)tl; l += tl;
         }
@@ -244,15 +260,10 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
         s.batches.push_back(b);
     }
     s.out_cap = out_cap;
-
     s.d_seeds.upload(lane_seeds);
     s.d_lane_reads.upload(lane_reads);
     s.d_chrom_reads.upload(quotas);
     s.d_pool_off.upload(pool_off);
-    s.d_info.upload(s.tables.info);
-    s.d_thresh.upload(s.tables.thresh);
-    s.d_quals.upload(s.tables.quals);
-    s.d_mm.upload(s.tables.mm_thresh);
     for (uint32_t e = 0; e < s.n_ends; e++) {
         s.d_pool[0][e].alloc(max_pool + 64);
         if (s.batches.size() > 1) s.d_pool[1][e].alloc(max_pool + 64);
@@ -263,12 +274,33 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     }
     s.d_lane_made.alloc(s.n_shard * 8);
     s.d_block_sums.alloc((max_lanes / SCAN_BLOCK + 2) * 8);
-    s.gen_done.resize(s.batches.size());
-    s.cp_done.resize(s.batches.size());
+    s.d_err.alloc(4);
+    for (hipEvent_t e : s.events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s.gen_done) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s.cp_done) (void)hipEventDestroy(e);
+    s.events.assign(2 + 2 * s.batches.size() + 2, nullptr);
+    for (hipEvent_t& e : s.events) JK_HIP(hipEventCreate(&e));
+    s.gen_done.assign(s.batches.size(), nullptr);
+    s.cp_done.assign(s.batches.size(), nullptr);
     for (hipEvent_t& e : s.gen_done) JK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t& e : s.cp_done) JK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return max_lanes;
+}
+
+static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const std::vector<uint64_t>& lane_reads,
+                                 uint64_t rec_max, const std::vector<uint32_t>& lane_seeds,
+                                 const std::vector<uint32_t>& quotas) {
+    // A batch is one generator launch.  Default: 2^18 lanes = one 1024-thread workgroup on each of the
+    // 256 CUs, so every launch is a single full wave of workgroups and the pool compaction of batch b
+    // (HBM-bound, second stream) runs under the generator of batch b+1 (ALU-bound).
+    std::vector<uint64_t> lane_cap(s.n_shard);
+    for (uint64_t l = 0; l < s.n_shard; l++) lane_cap[l] = (lane_reads[l] / s.n_ends) * rec_max;
+    const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, 1ULL << 18, lane_cap, lane_reads, lane_seeds, quotas);
+    s.d_info.upload(s.tables.info);
+    s.d_thresh.upload(s.tables.thresh);
+    s.d_quals.upload(s.tables.quals);
+    s.d_mm.upload(s.tables.mm_thresh);
     s.d_evw.alloc((size_t)s.n_ends * 4 * s.ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
-    s.d_err.alloc(4);
 
     s.lds_bytes = (s.tables.thresh.size() + (s.tables.thresh.size() & 1)) * 8 + 256 * 8 + s.tables.info.size() * 4 + align_up(s.tables.quals.size() * 2, 16);
     s.lds_tables = s.lds_bytes <= 150 * 1024;
@@ -286,9 +318,6 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     P.quals = s.d_quals.as<uint16_t>(); P.mm_thresh = s.d_mm.as<uint64_t>();
     P.n_info = (uint32_t)s.tables.info.size(); P.n_entries = (uint32_t)s.tables.thresh.size();
 
-    const size_t n_ev = 2 + 2 * s.batches.size() + 2;
-    s.events.resize(n_ev);
-    for (hipEvent_t& e : s.events) JK_HIP(hipEventCreate(&e));
     if (s.lds_tables) {
         const int lb = (int)s.lds_bytes;
         JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
@@ -335,7 +364,7 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
         throw Error(JK_ERR_UNSUPPORTED, "fragments shorter than the barcode (or empty) are not implemented on the GPU path");
 
     // ---- lanes, quotas, seeds: same order of seed consumption as src/hts.h:334-353
-    std::vector<uint64_t> per_lane = plan_lanes(s, a, a.n_reads);
+    std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, a.n_reads);
     const uint64_t T = s.n_lanes_total;
     std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
     std::vector<uint64_t> lane_reads(s.n_shard);
@@ -367,23 +396,10 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
     plan_pools_and_alloc(s, a, lane_reads, record_max(max_hdr, max_chrom, s.paired, L), lane_seeds, chrom_reads);
 }
 
-// ---- illumina_hap_cpp (src/hts_illumina.cpp:662-739), one set of output files (sep_files handled by
-// the caller: it opens one session per haplotype with one-hot probabilities, src/hts.h:512-552).
-static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illumina_args& a,
-                              const std::vector<double>& hap_probs, uint64_t n_reads, SeedReader& seeds) {
-    setup_model(s, a);
-    s.hap = true;
-    const uint32_t L = s.tables.read_length;
+// Mutation tables of a haplotype set -> device form (see HapDev); also uploads the genome + nucleotide blob.
+static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min_chrom, uint64_t& max_chrom,
+                              std::vector<uint64_t>& cell_size) {
     const uint64_t nh = hs.n_haps, nc = hs.ref.n_chroms;
-    if (nh == 0 || nc == 0) throw Error(JK_ERR_ARG, "haplotype set is empty");
-    if (nh * nc > 0x7fffffffULL) throw Error(JK_ERR_UNSUPPORTED, "too many (haplotype, chromosome) cells");
-    if (hap_probs.size() != nh) throw Error(JK_ERR_ARG, "haplotype_probs must have one entry per haplotype");
-    // barcodes: padded with "" to one per haplotype (src/hts_illumina.h:550)
-    std::vector<std::string> bcs(nh);
-    for (uint64_t h = 0; h < nh && h < a.n_barcodes; h++) bcs[h] = (a.barcodes && a.barcodes[h]) ? a.barcodes[h] : "";
-    size_t max_bc = 0;
-    for (const std::string& b : bcs) { check_barcode(b, L); max_bc = std::max(max_bc, b.size()); }
-
     // ---- mutation tables -> device form (see HapDev)
     const uint64_t n_cells = nh * nc;
     std::vector<uint64_t> cell_off(n_cells + 1, 0);
@@ -393,8 +409,8 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
     upload_genome(s, hs.ref, hs.nuc_blob, blob_len);          // sets s.nuc_base = offset of the blob in seq
     std::vector<int64_t> ref_shift(n_mut);
     std::vector<uint32_t> nuc_len(n_mut);
-    std::vector<uint64_t> nuc_dev_off(n_mut), new_pos(hs.new_pos, hs.new_pos + n_mut), cell_size(hs.chrom_size, hs.chrom_size + n_cells);
-    uint64_t min_chrom = ~0ULL, max_chrom = 0;
+    std::vector<uint64_t> nuc_dev_off(n_mut), new_pos(hs.new_pos, hs.new_pos + n_mut);
+    cell_size.assign(hs.chrom_size, hs.chrom_size + n_cells);
     for (uint64_t k = 0; k < n_cells; k++) {
         const uint64_t ref_len = hs.ref.chrom_lens[k % nc];
         min_chrom = std::min(min_chrom, cell_size[k]);
@@ -424,6 +440,41 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
     s.d_nuc_len.upload(nuc_len);
     s.d_nuc_off.upload(nuc_dev_off);
     s.d_cell_size.upload(cell_size);
+}
+
+static void set_hap_params(const jk_session& s, HapDev& h, uint32_t n_haps) {
+    h.cell_mut_off = s.d_cell_off.as<uint64_t>();
+    h.new_pos = s.d_new_pos.as<uint64_t>();
+    h.ref_shift = s.d_ref_shift.as<int64_t>();
+    h.nuc_len = s.d_nuc_len.as<uint32_t>();
+    h.nuc_off = s.d_nuc_off.as<uint64_t>();
+    h.cell_size = s.d_cell_size.as<uint64_t>();
+    h.bc_blob = s.d_bc_blob.as<uint8_t>();
+    h.bc_len = s.d_bc_len.as<uint32_t>();
+    h.n_haps = n_haps;
+}
+
+// ---- illumina_hap_cpp (src/hts_illumina.cpp:662-739), one set of output files (sep_files handled by
+// the caller: it opens one session per haplotype with one-hot probabilities, src/hts.h:512-552).
+static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illumina_args& a,
+                              const std::vector<double>& hap_probs, uint64_t n_reads, SeedReader& seeds) {
+    setup_model(s, a);
+    s.hap = true;
+    const uint32_t L = s.tables.read_length;
+    const uint64_t nh = hs.n_haps, nc = hs.ref.n_chroms;
+    if (nh == 0 || nc == 0) throw Error(JK_ERR_ARG, "haplotype set is empty");
+    if (nh * nc > 0x7fffffffULL) throw Error(JK_ERR_UNSUPPORTED, "too many (haplotype, chromosome) cells");
+    if (hap_probs.size() != nh) throw Error(JK_ERR_ARG, "haplotype_probs must have one entry per haplotype");
+    // barcodes: padded with "" to one per haplotype (src/hts_illumina.h:550)
+    std::vector<std::string> bcs(nh);
+    for (uint64_t h = 0; h < nh && h < a.n_barcodes; h++) bcs[h] = (a.barcodes && a.barcodes[h]) ? a.barcodes[h] : "";
+    size_t max_bc = 0;
+    for (const std::string& b : bcs) { check_barcode(b, L); max_bc = std::max(max_bc, b.size()); }
+
+    uint64_t min_chrom = ~0ULL, max_chrom = 0;
+    std::vector<uint64_t> cell_size;
+    upload_hap_tables(s, hs, min_chrom, max_chrom, cell_size);
+    const uint64_t n_cells = nh * nc;
     {
         std::vector<uint8_t> blob(nh * JK_MAX_BARCODE, 0);
         std::vector<uint32_t> blen(nh);
@@ -457,7 +508,7 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
     // reads_per_group over haplotypes, then per haplotype reads_per_group over its chromosomes, then
     // each read maker's own add_n_reads (halves the pair count again when paired; its result is never
     // read by the haplotype path, but it consumes 8 seed words when it has reads).
-    std::vector<uint64_t> per_lane = plan_lanes(s, a, n_reads);
+    std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, n_reads);
     const uint64_t T = s.n_lanes_total;
     std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
     std::vector<uint64_t> lane_reads(s.n_shard);
@@ -488,16 +539,244 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
     IlluminaKernelParams& P = s.kp;
     P.bc_len = 0;
     std::memset(P.barcode, 0, sizeof(P.barcode));
-    P.h.cell_mut_off = s.d_cell_off.as<uint64_t>();
-    P.h.new_pos = s.d_new_pos.as<uint64_t>();
-    P.h.ref_shift = s.d_ref_shift.as<int64_t>();
-    P.h.nuc_len = s.d_nuc_len.as<uint32_t>();
-    P.h.nuc_off = s.d_nuc_off.as<uint64_t>();
-    P.h.cell_size = s.d_cell_size.as<uint64_t>();
-    P.h.bc_blob = s.d_bc_blob.as<uint8_t>();
-    P.h.bc_len = s.d_bc_len.as<uint32_t>();
-    P.h.n_haps = (uint32_t)nh;
+    set_hap_params(s, P.h, (uint32_t)nh);
     plan_pools_and_alloc(s, a, lane_reads, record_max(max_hdr, max_chrom, s.paired, L), lane_seeds, vc);
+}
+
+// ---- pacbio_ref_cpp / pacbio_hap_cpp (src/hts_pacbio.cpp:579-715): host set-up -----------------------
+// Everything that depends only on the run's parameters or on an integer is tabulated here with the host's
+// libm (exactly what the reference calls) and the nmath restatements of jk_nmath.h.
+struct PacbioHostModel {
+    std::vector<uint64_t> len_thresh; std::vector<uint32_t> len_alias; std::vector<uint64_t> lens;
+    std::vector<double> thr_tab; std::vector<PassEntry> pass_tab;
+    double min_exp = 0;
+    uint64_t len_hi = 0;      // pool sizing: a read length few reads exceed
+    uint64_t len_cap = 0;     // hard cap (event scratch)
+};
+
+static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a, uint64_t max_chrom) {
+    if (a.compress > 0) throw Error(JK_ERR_UNSUPPORTED, "compressed FASTQ output is not implemented on the GPU path (write uncompressed, then gzip/bgzip)");
+    if (!a.chi2_params_n || !a.chi2_params_s || !a.sqrt_params || !a.norm_params) throw Error(JK_ERR_ARG, "PacBio parameter vectors must not be NULL");
+    s.pacbio = true; s.paired = false; s.n_ends = 1;
+    s.out_prefix = a.out_prefix ? a.out_prefix : "";
+    s.abort_flag = a.abort_flag;
+    s.device = a.device;
+    JK_HIP(hipSetDevice(s.device));
+    JK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    JK_HIP(hipStreamCreateWithFlags(&s.cp_stream, hipStreamNonBlocking));
+
+    PacbioHostModel M;
+    PacbioKernelParams& P = s.kpb;
+    // read lengths (PacBioReadLenSampler, src/hts_pacbio.h:45-109)
+    if (a.n_read_lens == 0) {
+        P.use_lognormal = 1;
+        P.ln_mu = std::log(a.scale); P.ln_sigma = a.sigma; P.ln_loc = a.loc;
+        P.min_read_len = std::ceil(a.min_read_len);
+        if (P.min_read_len < 1) P.min_read_len = 1;
+        const double hi = std::exp(P.ln_mu + 4.0 * a.sigma) + a.loc, cap = std::exp(P.ln_mu + 9.0 * a.sigma) + a.loc;
+        M.len_hi = (uint64_t)std::max(hi, P.min_read_len + 1.0);
+        M.len_cap = (uint64_t)std::max(cap, P.min_read_len + 1.0);
+    } else {
+        if (!a.read_probs || !a.read_lens) throw Error(JK_ERR_ARG, "Probability and read lengths vector should be the same length.");
+        P.use_lognormal = 0;
+        AliasTable at = alias_build(std::vector<double>(a.read_probs, a.read_probs + a.n_read_lens));
+        for (uint64_t i = 0; i < a.n_read_lens; i++) {
+            Threshold th = threshold_lt(at.prob[i]);
+            M.len_thresh.push_back(th.all ? ~uint64_t(0) : th.th);
+            M.len_alias.push_back(th.all ? (uint32_t)i : (uint32_t)at.alias[i]);
+            M.lens.push_back(a.read_lens[i]);
+            M.len_hi = std::max(M.len_hi, a.read_lens[i]);
+        }
+        M.len_cap = M.len_hi;
+        if (a.n_read_lens >= (1ULL << 31)) throw Error(JK_ERR_UNSUPPORTED, "too many custom read lengths");
+        P.n_lens = (uint32_t)a.n_read_lens;
+    }
+    M.len_hi = std::min(M.len_hi, max_chrom);
+    M.len_cap = std::min(M.len_cap, max_chrom);
+    // passes (PacBioPassSampler): qchisq(0.9925, n(L)) for every read length that changes n
+    for (int i = 0; i < 3; i++) P.cn[i] = a.chi2_params_n[i];
+    for (int i = 0; i < 5; i++) P.cs[i] = a.chi2_params_s[i];
+    P.max_passes_d = static_cast<double>(a.max_passes);
+    if (a.max_passes < 1 || a.max_passes > 100000) throw Error(JK_ERR_ARG, "max_passes out of range");
+    {
+        const double n2 = P.cn[2];
+        uint64_t cap = n2 >= 1 ? (uint64_t)std::min(std::floor(n2), (double)M.len_cap) : 0;
+        if (cap > (64ULL << 20)) throw Error(JK_ERR_UNSUPPORTED, "chi2_params_n[3] too large for the GPU path's threshold table");
+        M.thr_tab.resize(cap + 2);
+        for (uint64_t L = 0; L <= cap + 1; L++) {
+            const double Ld = (L <= cap) ? (double)L : std::max((double)(cap + 1), n2);   // last entry: the capped value
+            double n = P.cn[0] * std::min(Ld, n2) + P.cn[1];
+            if (n < 0.001) n = 0.001;
+            M.thr_tab[L] = qchisq_upper_tail_point(0.9925, n);
+        }
+        P.thr_cap = (uint32_t)(cap + 1);
+    }
+    // qualities/errors (PacBioQualityError)
+    P.np0 = a.norm_params[0]; P.np1 = a.norm_params[1]; P.sp1 = a.sqrt_params[1];
+    P.prob_ins = a.prob_ins; P.prob_del = a.prob_del; P.prob_subst = a.prob_subst;
+    {   // calc_min_exp (src/hts_pacbio.cpp:50-91)
+        auto total_at = [&](double e) { return std::pow(a.prob_ins, e) + std::pow(a.prob_del, e) + std::pow(a.prob_subst, e); };
+        double min_exp_ = 1, total = total_at(min_exp_), left, right;
+        if (total < a.prob_thresh) {
+            while (total < a.prob_thresh) { min_exp_ /= 2; total = total_at(min_exp_); }
+            left = min_exp_; right = min_exp_ * 2;
+        } else {
+            while (total > a.prob_thresh) { min_exp_ *= 2; total = total_at(min_exp_); }
+            left = min_exp_ / 2; right = min_exp_;
+        }
+        for (int i = 0; i < 15; i++) {
+            const double m = (left + right) / 2;
+            total = total_at(m);
+            if (total == a.prob_thresh) { min_exp_ = m; break; }
+            else if (total > a.prob_thresh) { left = m; min_exp_ = (m + right) / 2; }
+            else { right = m; min_exp_ = (left + m) / 2; }
+        }
+        M.min_exp = min_exp_;
+    }
+    M.pass_tab.resize(a.max_passes + 2);
+    for (uint64_t k = 0; k < M.pass_tab.size(); k++) {
+        const double passes = (double)k;
+        PassEntry& e = M.pass_tab[k];
+        e.sig = 1 / (1 + std::pow(2, (-2.5 / 3 * passes + 6.5 / 3)));                 // sigmoid (hts_pacbio.h:333-335)
+        e.sqrtv = std::sqrt(passes + a.sqrt_params[0]);
+        const double lower_thresh = (M.min_exp - (e.sqrtv - a.sqrt_params[1])) / e.sig;   // update_probs (hts_pacbio.cpp:101-104)
+        e.a_bar = (lower_thresh - a.norm_params[0]) / a.norm_params[1];
+        if (lower_thresh < (a.norm_params[0] + 5 * a.norm_params[1])) {
+            e.method = 0;
+            e.p = pnorm_std(e.a_bar);
+            jk_x87_one_minus(e.p, &e.c_m, &e.c_e);
+        } else { e.method = 1; e.p = 0; e.c_m = 0; e.c_e = 0; }
+    }
+    {   // dup < prob_dup
+        Threshold t = threshold_lt(a.prob_dup);
+        P.th_dup = t.th; P.dup_all = t.all;
+    }
+    P.pool_size = a.read_pool_size;
+    return M;
+}
+
+static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioHostModel& M, size_t max_hdr, uint64_t max_chrom,
+                          const std::vector<uint64_t>& lane_reads, const std::vector<uint32_t>& lane_seeds,
+                          const std::vector<uint32_t>& quotas) {
+    // pools: sized for reads of length len_hi; the kernel checks before every record and the session retries
+    // with a larger scale if a lane ran out (s.pool_scale)
+    const uint64_t rec = max_hdr + n_digits(max_chrom) + 3 + 2 * M.len_hi + 8;
+    std::vector<uint64_t> lane_cap(s.n_shard);
+    for (uint64_t l = 0; l < s.n_shard; l++) lane_cap[l] = (uint64_t)((double)(lane_reads[l] * rec) * s.pool_scale) + 2 * M.len_cap + 64;
+    const uint32_t max_lanes = plan_pools_common(s, max_batch_bytes ? max_batch_bytes : (32ULL << 30), 1ULL << 17,
+                                                 lane_cap, lane_reads, lane_seeds, quotas);
+    s.ev_words = (uint32_t)((2 * M.len_cap + 64 + 31) / 32);
+    s.d_ev2.alloc((size_t)s.ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
+    s.d_len_thresh.upload(M.len_thresh); s.d_len_alias.upload(M.len_alias); s.d_lens.upload(M.lens);
+    s.d_thr_tab.upload(M.thr_tab); s.d_pass_tab.upload(M.pass_tab);
+    PacbioKernelParams& P = s.kpb;
+    P.g.seq = s.d_seq.as<uint8_t>();
+    P.g.chrom_off = s.d_chrom_off.as<uint64_t>();
+    P.g.chrom_len = s.d_chrom_len.as<uint64_t>();
+    P.g.hdr_blob = s.d_hdr_blob.as<uint8_t>();
+    P.g.hdr_off = s.d_hdr_off.as<uint32_t>();
+    P.g.n_chroms = s.n_chroms;
+    P.ev = s.d_ev2.as<uint64_t>(); P.ev_words = s.ev_words;
+    P.err = s.d_err.as<uint32_t>();
+    P.len_thresh = s.d_len_thresh.as<uint64_t>(); P.len_alias = s.d_len_alias.as<uint32_t>(); P.lens = s.d_lens.as<uint64_t>();
+    P.thr_tab = s.d_thr_tab.as<double>(); P.pass_tab = s.d_pass_tab.as<PassEntry>();
+}
+
+static void upload_headers(jk_session& s, const std::vector<std::string>& hdrs, size_t& max_hdr) {
+    std::vector<uint8_t> blob;
+    std::vector<uint32_t> hoff(hdrs.size() + 1);
+    for (size_t k = 0; k < hdrs.size(); k++) {
+        hoff[k] = (uint32_t)blob.size();
+        max_hdr = std::max(max_hdr, hdrs[k].size());
+        blob.insert(blob.end(), hdrs[k].begin(), hdrs[k].end());
+    }
+    hoff[hdrs.size()] = (uint32_t)blob.size();
+    s.d_hdr_blob.upload(blob);
+    s.d_hdr_off.upload(hoff);
+}
+
+static void open_pacbio_ref(jk_session& s, const jk_ref_genome& g, const jk_pacbio_args& a, SeedReader& seeds) {
+    uint64_t max_chrom = 0;
+    for (uint64_t i = 0; i < g.n_chroms; i++) max_chrom = std::max<uint64_t>(max_chrom, g.chrom_lens[i]);
+    PacbioHostModel M = setup_pacbio_model(s, a, max_chrom);
+    upload_genome(s, g, nullptr, 0);
+    const std::string gname = g.name ? g.name : "REF";
+    std::vector<std::string> hdrs;
+    for (uint64_t i = 0; i < g.n_chroms; i++) hdrs.push_back("@" + gname + "-" + (g.chrom_names ? g.chrom_names[i] : "") + "-");
+    size_t max_hdr = 0;
+    upload_headers(s, hdrs, max_hdr);
+    // lanes, quotas, seeds (src/hts.h:334-353 with n_read_ends = 1; PacBioOneGenome::add_n_reads, hts_pacbio.h:499-503)
+    std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, a.n_reads);
+    const uint64_t T = s.n_lanes_total;
+    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
+    std::vector<uint64_t> lane_reads(s.n_shard);
+    std::vector<uint32_t> chrom_reads((size_t)s.n_chroms * s.n_shard, 0);
+    std::vector<double> chrom_probs(g.chrom_lens, g.chrom_lens + g.n_chroms);
+    for (uint64_t t = 0; t < T; t++) {
+        const uint64_t n = per_lane[t];
+        const bool mine = t >= s.lane_begin && t < s.lane_end;
+        if (!mine) { if (n > 0) { uint32_t w[8]; seeds.take8(w); } continue; }
+        const uint64_t l = t - s.lane_begin;
+        lane_reads[l] = n;
+        std::vector<uint64_t> cr = reads_per_group(n, chrom_probs, seeds);
+        for (uint32_t c = 0; c < s.n_chroms; c++) chrom_reads[(size_t)c * s.n_shard + l] = (uint32_t)cr[c];
+    }
+    s.seed_words_used = seeds.pos;
+    const uint64_t mbb = a.max_batch_bytes;
+    jk_session* sp = &s;
+    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, lane_reads, lane_seeds, chrom_reads); };
+    s.replan();
+}
+
+static void open_pacbio_hap(jk_session& s, const jk_hap_set& hs, const jk_pacbio_args& a,
+                            const std::vector<double>& hap_probs, uint64_t n_reads, SeedReader& seeds) {
+    const uint64_t nh = hs.n_haps, nc = hs.ref.n_chroms;
+    if (nh == 0 || nc == 0) throw Error(JK_ERR_ARG, "haplotype set is empty");
+    if (hap_probs.size() != nh) throw Error(JK_ERR_ARG, "haplotype_probs must have one entry per haplotype");
+    uint64_t max_c = 0;
+    for (uint64_t k = 0; k < nh * nc; k++) max_c = std::max<uint64_t>(max_c, hs.chrom_size[k]);
+    PacbioHostModel M = setup_pacbio_model(s, a, max_c);
+    s.hap = true;
+    uint64_t min_chrom = ~0ULL, max_chrom = 0;
+    std::vector<uint64_t> cell_size;
+    upload_hap_tables(s, hs, min_chrom, max_chrom, cell_size);
+    {   // no barcodes on this path
+        std::vector<uint8_t> blob(nh * JK_MAX_BARCODE, 0); std::vector<uint32_t> blen(nh, 0);
+        s.d_bc_blob.upload(blob); s.d_bc_len.upload(blen);
+    }
+    const uint64_t n_cells = nh * nc;
+    std::vector<std::string> hdrs;
+    for (uint64_t k = 0; k < n_cells; k++)
+        hdrs.push_back(std::string("@") + (hs.hap_names ? hs.hap_names[k / nc] : "") + "-" + (hs.ref.chrom_names ? hs.ref.chrom_names[k % nc] : "") + "-");
+    size_t max_hdr = 0;
+    upload_headers(s, hdrs, max_hdr);
+    // PacBioHaplotypes::add_n_reads (src/hts_pacbio.h:683-700)
+    std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, n_reads);
+    const uint64_t T = s.n_lanes_total;
+    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
+    std::vector<uint64_t> lane_reads(s.n_shard);
+    std::vector<uint32_t> vc((size_t)n_cells * s.n_shard, 0);
+    std::vector<std::vector<double>> chrom_probs(nh, std::vector<double>(nc));
+    for (uint64_t h = 0; h < nh; h++) for (uint64_t c = 0; c < nc; c++) chrom_probs[h][c] = (double)cell_size[h * nc + c];
+    for (uint64_t t = 0; t < T; t++) {
+        const uint64_t n = per_lane[t];
+        const bool mine = t >= s.lane_begin && t < s.lane_end;
+        std::vector<uint64_t> hap_reads = reads_per_group(n, hap_probs, seeds);
+        for (uint64_t h = 0; h < nh; h++) {
+            if (mine) {
+                std::vector<uint64_t> cr = reads_per_group(hap_reads[h], chrom_probs[h], seeds);
+                for (uint64_t c = 0; c < nc; c++) vc[(size_t)(h * nc + c) * s.n_shard + (t - s.lane_begin)] = (uint32_t)cr[c];
+            } else if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }
+        }
+        for (uint64_t h = 0; h < nh; h++) if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }   // read_makers[h].add_n_reads
+        if (mine) lane_reads[t - s.lane_begin] = n;
+    }
+    s.seed_words_used = seeds.pos;
+    set_hap_params(s, s.kpb.h, (uint32_t)nh);
+    const uint64_t mbb = a.max_batch_bytes;
+    jk_session* sp = &s;
+    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, lane_reads, lane_seeds, vc); };
+    s.replan();
 }
 
 static void launch_generate(jk_session& s) {
@@ -511,6 +790,40 @@ static void launch_generate(jk_session& s) {
         if (s.abort_flag && *s.abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
         const Batch& B = s.batches[b];
         const int pp = (int)(b & 1);       // ping-pong pool set
+        if (s.pacbio) {
+            PacbioKernelParams Q = s.kpb;
+            Q.n_lanes = B.n_lanes;
+            Q.seeds = s.d_seeds.as<uint32_t>() + B.lane0 * 8;
+            Q.lane_reads = s.d_lane_reads.as<uint64_t>() + B.lane0;
+            Q.chrom_reads = s.d_chrom_reads.as<uint32_t>() + B.lane0;
+            Q.chrom_stride = (uint32_t)s.n_shard;
+            Q.pool_off = s.d_pool_off.as<uint64_t>() + s.batch_pool_off_index[b];
+            Q.pool = s.d_pool[pp][0].as<uint8_t>();
+            Q.lane_bytes = s.d_lane_bytes[0].as<uint64_t>() + B.lane0;
+            Q.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
+            if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));
+            JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+            const uint32_t pgrid = (B.n_lanes + 255) / 256;
+            if (s.hap) hipLaunchKernelGGL((pacbio_kernel<true>), dim3(pgrid), dim3(256), 0, s.stream, Q);
+            else hipLaunchKernelGGL((pacbio_kernel<false>), dim3(pgrid), dim3(256), 0, s.stream, Q);
+            JK_HIP(hipGetLastError());
+            JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+            JK_HIP(hipEventRecord(s.gen_done[b], s.stream));
+            JK_HIP(hipStreamWaitEvent(s.cp_stream, s.gen_done[b], 0));
+            const uint32_t nbp = (B.n_lanes + SCAN_BLOCK - 1) / SCAN_BLOCK;
+            uint64_t* lb = s.d_lane_bytes[0].as<uint64_t>() + B.lane0;
+            uint64_t* lo = s.d_lane_off[0].as<uint64_t>() + B.lane0;
+            uint64_t* bs = s.d_block_sums.as<uint64_t>();
+            uint64_t* base = s.d_base[0].as<uint64_t>() + b;
+            hipLaunchKernelGGL(scan_block_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lb, lo, bs, B.n_lanes);
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.cp_stream, bs, nbp, base);
+            hipLaunchKernelGGL(scan_add_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lo, bs, B.n_lanes);
+            hipLaunchKernelGGL(compact_pools_kernel, dim3((B.n_lanes + 63) / 64), dim3(256), 0, s.cp_stream,
+                               s.d_pool[pp][0].as<uint8_t>(), Q.pool_off, lb, lo, s.d_out[0].as<uint8_t>(), base, B.n_lanes);
+            JK_HIP(hipGetLastError());
+            JK_HIP(hipEventRecord(s.cp_done[b], s.cp_stream));
+            continue;
+        }
         IlluminaKernelParams P = s.kp;
         P.n_lanes = B.n_lanes;
         P.seeds = s.d_seeds.as<uint32_t>() + B.lane0 * 8;
@@ -564,6 +877,11 @@ static void launch_generate(jk_session& s) {
 
     uint32_t err = 0;
     JK_HIP(hipMemcpy(&err, s.d_err.p, 4, hipMemcpyDeviceToHost));
+    if (err & JK_KERR_PB_ALPHA) throw Error(JK_ERR_UNSUPPORTED, "chi-square shape n/2 < 1 (chi2_params_n) is not implemented on the GPU path");
+    if (err & JK_KERR_PB_MATH) throw Error(JK_ERR_UNSUPPORTED, "a PacBio parameter led to an exp/pow argument outside the range implemented on the GPU");
+    if (err & JK_KERR_PB_TOO_LONG) throw Error(JK_ERR_UNSUPPORTED, "a read was longer than the GPU path's cap (9 sigma of the log-normal, or it needed > 2x its length in reference positions)");
+    if (err & JK_KERR_PB_SPACE) throw Error(JK_ERR_UNSUPPORTED, "a read ran past its chromosome window (reads as long as their chromosome are not implemented on the GPU path)");
+    if ((err & JK_KERR_POOL_OVERFLOW) && s.pacbio) throw Error(JK_ERR_RETRY, "pool overflow");
     if (err & JK_KERR_POOL_OVERFLOW) throw Error(JK_ERR_DEVICE, "internal error: a lane overflowed its pool region");
     if (err & JK_KERR_TOO_MANY_DELETIONS) throw Error(JK_ERR_UNSUPPORTED, "a read needed more than 2x read_length reference positions (deletion probability too high for the GPU path)");
     for (uint32_t e = 0; e < s.n_ends; e++)
@@ -634,6 +952,15 @@ JK_HD void eval_one(int what, const uint64_t* in, uint64_t i, uint64_t aux, uint
             for (uint64_t k = 0; k < aux; k++) out[i * aux + k] = jk_d2u(jk_gamma(gp, st, r));
             break;
         }
+        case JK_OP_EXP: { double r = 0; bool ok = jk_exp(jk_u2d(in[i]), &r); out[i] = ok ? jk_d2u(r) : ~0ULL; break; }
+        case JK_OP_POW: { bool ok = true; double r = jk_pow(jk_u2d(in[2 * i]), jk_u2d(in[2 * i + 1]), &ok); out[i] = ok ? jk_d2u(r) : ~0ULL; break; }
+        case JK_OP_LOG10: out[i] = jk_d2u(jk_log10(jk_u2d(in[i]))); break;
+        case JK_OP_QNORM: out[i] = jk_d2u(jk_qnorm(jk_u2d(in[i]))); break;
+        case JK_OP_RUNIF_AB: {
+            jk_x87 c; c.m = in[4 * i + 2]; c.e = (int32_t)(int64_t)in[4 * i + 3];
+            out[i] = jk_d2u(jk_runif_ab(in[4 * i], jk_x87_from_double(jk_u2d(in[4 * i + 1])), c));
+            break;
+        }
         default: break;
     }
 }
@@ -653,7 +980,7 @@ static jk_gamma_param eval_gamma_param() {
 
 static void eval_sizes(int what, uint64_t n, uint64_t aux, uint64_t* n_in, uint64_t* n_out) {
     const bool stream = (what == JK_OP_PCG_STREAM || what == JK_OP_GAMMA_STREAM);
-    *n_in = stream ? n * 8 : n;
+    *n_in = stream ? n * 8 : (what == JK_OP_POW ? n * 2 : (what == JK_OP_RUNIF_AB ? n * 4 : n));
     *n_out = stream ? n * aux : n;
 }
 
@@ -699,8 +1026,86 @@ int jk_illumina_hap_open(const jk_hap_set* haps, const jk_illumina_args* args, j
     });
 }
 
+static void generate_with_retry(jk_session& s) {
+    for (int attempt = 0;; attempt++) {
+        try { launch_generate(s); return; }
+        catch (const Error& e) {
+            if (e.code != JK_ERR_RETRY || attempt >= 6 || !s.replan) {
+                if (e.code == JK_ERR_RETRY) throw Error(JK_ERR_DEVICE, "PacBio pools overflowed even after growing them");
+                throw;
+            }
+            s.pool_scale *= 2;
+            s.replan();
+        }
+    }
+}
+
+static std::vector<double> pb_hap_probs_of(const jk_hap_set& hs, const jk_pacbio_args& a) {
+    if (!a.haplotype_probs) return std::vector<double>(hs.n_haps, 1.0);
+    return std::vector<double>(a.haplotype_probs, a.haplotype_probs + hs.n_haps);
+}
+
+int jk_pacbio_ref_open(const jk_ref_genome* genome, const jk_pacbio_args* args, jk_session** out) {
+    return guarded([&] {
+        if (!genome || !args || !out) throw Error(JK_ERR_ARG, "NULL argument");
+        if (genome->n_chroms == 0) throw Error(JK_ERR_ARG, "reference genome has no chromosomes");
+        std::unique_ptr<jk_session> s(new jk_session());
+        SeedReader seeds{args->seeds};
+        open_pacbio_ref(*s, *genome, *args, seeds);
+        *out = s.release();
+    });
+}
+
+int jk_pacbio_hap_open(const jk_hap_set* haps, const jk_pacbio_args* args, jk_session** out) {
+    return guarded([&] {
+        if (!haps || !args || !out) throw Error(JK_ERR_ARG, "NULL argument");
+        if (args->sep_files) throw Error(JK_ERR_UNSUPPORTED, "sep_files needs one session per haplotype: use jk_pacbio_hap");
+        std::unique_ptr<jk_session> s(new jk_session());
+        SeedReader seeds{args->seeds};
+        open_pacbio_hap(*s, *haps, *args, pb_hap_probs_of(*haps, *args), args->n_reads, seeds);
+        *out = s.release();
+    });
+}
+
+int jk_pacbio_ref(const jk_ref_genome* genome, const jk_pacbio_args* args) {
+    jk_session* s = nullptr;
+    int rc = jk_pacbio_ref_open(genome, args, &s);
+    if (rc == JK_OK) rc = jk_session_generate(s);
+    if (rc == JK_OK) rc = jk_session_write(s);
+    std::string keep = g_last_error;
+    jk_session_close(s);
+    g_last_error = keep;
+    return rc;
+}
+
+int jk_pacbio_hap(const jk_hap_set* haps, const jk_pacbio_args* args) {
+    return guarded([&] {
+        if (!haps || !args) throw Error(JK_ERR_ARG, "NULL argument");
+        SeedReader seeds{args->seeds};
+        const std::vector<double> probs = pb_hap_probs_of(*haps, *args);
+        if (!args->sep_files) {
+            std::unique_ptr<jk_session> s(new jk_session());
+            open_pacbio_hap(*s, *haps, *args, probs, args->n_reads, seeds);
+            generate_with_retry(*s);
+            write_files(*s);
+            return;
+        }
+        std::vector<uint64_t> per_file = reads_per_group(args->n_reads, probs, seeds);   // src/hts.h:526-529, one read end
+        for (uint64_t h = 0; h < haps->n_haps; h++) {
+            if (args->abort_flag && *args->abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
+            std::vector<double> one_hot(haps->n_haps, 0.0);
+            one_hot[h] = 1;
+            std::unique_ptr<jk_session> s(new jk_session());
+            open_pacbio_hap(*s, *haps, *args, one_hot, per_file[h], seeds);
+            s->out_prefix += std::string("_") + (haps->hap_names ? haps->hap_names[h] : "");
+            generate_with_retry(*s);
+            write_files(*s);
+        }
+    });
+}
+
 int jk_session_generate(jk_session* s) {
-    return guarded([&] { if (!s) throw Error(JK_ERR_ARG, "NULL session"); launch_generate(*s); });
+    return guarded([&] { if (!s) throw Error(JK_ERR_ARG, "NULL session"); generate_with_retry(*s); });
 }
 
 int jk_session_sizes(const jk_session* s, uint64_t bytes[2], uint64_t* reads, uint32_t* n_ends) {
@@ -846,6 +1251,15 @@ int jk_hap_chrom_full(const jk_hap_set* hs, uint64_t hap, uint64_t chrom, char* 
 }
 
 void jk_eval_set_gamma(double shape, double scale) { g_eval_shape = shape; g_eval_scale = scale; }
+
+// 1 - p in x87 extended precision (what `b - a` of runif_ab(eng, p, 1) is), as significand and exponent
+void jk_x87_one_minus(double p, uint64_t* m, int32_t* e) {
+    const long double c = 1.0L - static_cast<long double>(p);
+    int ex = 0;
+    const long double fr = frexpl(c, &ex);              // c = fr * 2^ex, fr in [0.5, 1)
+    *m = c > 0 ? static_cast<uint64_t>(ldexpl(fr, 64)) : 0;
+    *e = ex - 64;
+}
 
 int jk_host_eval(int what, const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out) {
     return guarded([&] {

@@ -40,7 +40,7 @@ enum : uint32_t {
 
 struct GenomeDev {
     const uint8_t* seq;          // all chromosomes, 1 byte per base, 64-B padded, ENCODED on upload:
-                                 // T=0 C=1 A=2 G=3 (jlp::bases order), anything else = 4
+                                 // T=0 C=1 A=2 G=3 (jlp::bases order), anything else keeps its ASCII value
     const uint64_t* chrom_off;   // [n_chroms] byte offset of chromosome in seq
     const uint64_t* chrom_len;   // [n_chroms]
     const uint8_t* hdr_blob;     // "@<genome>-<chrom>-" per chromosome
@@ -564,13 +564,16 @@ illumina_kernel(IlluminaKernelParams P) {
     if (err) atomicOr(P.err, err);
 }
 
-// ASCII -> code, in place (run once per uploaded buffer)
-__global__ void encode_bases_kernel(uint8_t* seq, uint64_t n) {
+// ASCII -> code, in place (run once per uploaded buffer): T,C,A,G -> 0..3 (jlp::bases order, complement =
+// code ^ 2); every other byte keeps its ASCII value (>= 4), which is all the Illumina path needs to know
+// ("not TCAG") and what the PacBio path copies through verbatim.  Input bytes 0..3 cannot be represented.
+__global__ void encode_bases_kernel(uint8_t* seq, uint64_t n, uint32_t* bad) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = i; k < n; k += stride) {
         const uint8_t c = seq[k];
-        seq[k] = c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : 4;
+        if (c < 4) *bad = 1;
+        seq[k] = c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : c;
     }
 }
 

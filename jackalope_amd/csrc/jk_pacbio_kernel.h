@@ -1,0 +1,370 @@
+// jk_pacbio_kernel.h -- the PacBio (SimLoRD-style) per-read loop as a gfx950 HIP kernel.
+//
+// Reference: PacBioOneGenome::{one_read,re_read,append_pool} (/root/reference/src/hts_pacbio.cpp:136-485),
+// PacBioReadLenSampler::sample (:27-45), PacBioPassSampler::sample (src/hts_pacbio.h:149-205),
+// PacBioQualityError::{sample,update_probs,trunc_norm,fill_quals} (src/hts_pacbio.h:266-398,
+// src/hts_pacbio.cpp:96-131), PacBioHaplotypes::{one_read,re_read} (src/hts_pacbio.cpp:488-551).
+//
+// Same execution model as the Illumina kernel: one GPU thread = one lane = one reference thread, the
+// lane appends FASTQ text to its column of a 64-lane pool tile.  Per read the reference makes two
+// passes over the read's positions: (1) one draw per position classifies it as plain / insertion /
+// deletion / substitution, (2) the bases are emitted with one more draw per insertion or
+// substitution.  Pass 1 stores 2 bits per position in a per-lane HBM scratch laid out
+// [word][lane] (32 positions per u64, lanes advance in lock-step so the stores coalesce); pass 2
+// reads them back.  Everything that only depends on an integer (pass count, read length <= chi2_n[2])
+// comes from host-built tables, so the device needs exp/pow/log10/qnorm (jk_math2.h) but no nmath.
+#pragma once
+#include "jk_illumina_kernel.h"
+#include "jk_math2.h"
+
+namespace jk {
+
+enum : uint32_t {
+    JK_KERR_PB_ALPHA = 4u,        // chi-square shape n/2 < 1 (needs pow in the gamma sampler)
+    JK_KERR_PB_MATH = 8u,         // pow/exp argument outside the transcribed main path
+    JK_KERR_PB_TOO_LONG = 16u,    // a read needed more positions than the event scratch holds
+    JK_KERR_PB_SPACE = 32u,       // "read_chrom_space should never exceed the chromosome length."
+};
+
+struct PassEntry {                // per integer pass count (host table)
+    double sig;                   // sigmoid(passes)
+    double sqrtv;                 // sqrt(passes + sqrt_params[0])
+    double a_bar;                 // (lower_thresh - mean) / sd
+    double p;                     // pnorm(a_bar)            (method 0)
+    uint64_t c_m; int32_t c_e;    // 1 - p in x87 extended  (method 0)
+    int32_t method;               // 0: inverse-CDF draw, 1: tail rejection (lower_thresh >= mean + 5 sd)
+};
+
+struct PacbioKernelParams {
+    GenomeDev g;
+    HapDev h;
+    uint32_t n_lanes;
+    const uint32_t* seeds;
+    const uint64_t* lane_reads;
+    const uint32_t* chrom_reads;  // [chrom or cell][lane]
+    uint32_t chrom_stride;
+    const uint64_t* pool_off;     // [n_tiles + 1]
+    uint8_t* pool;
+    uint64_t* lane_bytes;
+    uint64_t* lane_made;
+    uint64_t* ev;                 // [ev_words][n_lanes] 2-bit event codes
+    uint32_t ev_words;
+    uint32_t* err;
+    // read lengths
+    uint32_t use_lognormal;
+    double ln_mu, ln_sigma, ln_loc, min_read_len;
+    uint32_t n_lens; const uint64_t* len_thresh; const uint32_t* len_alias; const uint64_t* lens;
+    // passes
+    double cn[3], cs[5];
+    double max_passes_d;
+    const double* thr_tab; uint32_t thr_cap;      // thr_tab[min(L, thr_cap)] = qchisq(0.9925, n(L))
+    // qualities / errors
+    const PassEntry* pass_tab;                    // [max_passes + 1]
+    double np0, np1, sp1, prob_ins, prob_del, prob_subst;
+    uint64_t th_dup; uint32_t dup_all;
+    uint64_t pool_size;
+};
+
+__device__ __forceinline__ void os_fill(OutStream& s, uint32_t byte, uint64_t count) {
+    s.pos += (uint32_t)count;
+    while (count && s.cnt) { os_put_raw(s, byte); count--; if (s.cnt >= 4u) os_store_word(s); }
+    const uint32_t w = byte * 0x01010101u;
+    while (count >= 4) { *reinterpret_cast<uint32_t*>(s.wp) = w; s.wp += TILE_ROW; count -= 4; }
+    while (count) { os_put_raw(s, byte); count--; }
+}
+
+template <bool HAP>
+__global__ void __launch_bounds__(256)
+pacbio_kernel(PacbioKernelParams P) {
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= P.n_lanes) return;
+
+    LaneRng rng;
+    rng.e = jk_pcg_seed(P.seeds + (size_t)lane * 8);
+    jk_gamma_state ln_st; ln_st.saved = 0.0; ln_st.saved_available = 0;     // lognormal_distribution::_M_nd
+    jk_gamma_state chi_st; chi_st.saved = 0.0; chi_st.saved_available = 0;  // chi_squared -> gamma -> _M_nd
+
+    const uint64_t quota = P.lane_reads[lane];
+    uint64_t made = 0, in_pool = 0;
+    const uint32_t n_cells = HAP ? P.h.n_haps * P.g.n_chroms : P.g.n_chroms;
+    uint32_t ci = 0;
+    uint64_t ccnt = n_cells ? P.chrom_reads[lane] : 0;
+    uint32_t cur_hap = 0xffffffffu;
+
+    const uint32_t tile = lane >> 6;
+    const uint64_t tile_off = P.pool_off[tile];
+    const uint64_t lane_cap = (P.pool_off[tile + 1] - tile_off) >> 6;
+    uint8_t* const base = P.pool + tile_off + (lane & 63u) * 4u;
+    OutStream o;
+    os_begin(o, base, 0);
+
+    uint32_t err = 0;
+    const size_t ev_stride = (size_t)P.n_lanes;
+    uint64_t* const evl = P.ev + lane;
+    const uint64_t max_pos = (uint64_t)P.ev_words * 32u;
+
+    uint64_t L = 0, read_start = 0, chrom_len = 0;
+    bool is_dup = false;
+    while (made < quota) {
+        if (!is_dup) {
+            // chromosome / cell.  Reference genome: first chromosome with a non-zero quota; the quota is never
+            // decremented on this path (src/hts_pacbio.cpp:145-151).  Haplotypes: cursor search (:498-521).
+            while (ci < n_cells && ccnt == 0) { ci++; if (ci < n_cells) ccnt = P.chrom_reads[(size_t)ci * P.chrom_stride + lane]; }
+            if (ci >= n_cells) { made = quota; break; }
+            if (HAP) {
+                const uint32_t hap = ci / P.g.n_chroms;
+                if (hap != cur_hap) {      // a new PacBioOneHaplotype: fresh distribution objects
+                    cur_hap = hap;
+                    ln_st.saved = 0.0; ln_st.saved_available = 0;
+                    chi_st.saved = 0.0; chi_st.saved_available = 0;
+                }
+            }
+            chrom_len = HAP ? P.h.cell_size[ci] : P.g.chrom_len[ci];
+            // ---- read length (src/hts_pacbio.cpp:27-45)
+            if (P.use_lognormal) {
+                double rnd = 0;
+                uint32_t iters = 0;
+                for (;;) {
+                    double ex;
+                    if (!jk_exp(P.ln_sigma * jk_normal(ln_st, rng) + P.ln_mu, &ex)) { err |= JK_KERR_PB_MATH; ex = 0; }
+                    rnd = ex + P.ln_loc;
+                    if (!(rnd < P.min_read_len) || iters >= 10) break;
+                    iters++;
+                }
+                if (rnd < P.min_read_len) rnd = P.min_read_len;
+                L = (uint64_t)rnd;
+            } else {
+                const uint32_t i0 = (uint32_t)jk_runif_index(rng(), P.n_lens);
+                const uint64_t x2 = rng();
+                L = P.lens[(x2 < P.len_thresh[i0]) ? i0 : P.len_alias[i0]];
+            }
+            if (L >= chrom_len) L = chrom_len;
+        }
+        if (err) break;
+        // ---- number of passes (src/hts_pacbio.h:149-205)
+        const double Ld = (double)L;
+        double n = P.cn[0] * (Ld < P.cn[2] ? Ld : P.cn[2]) + P.cn[1];
+        if (n < 0.001) n = 0.001;
+        double sc;
+        if (Ld <= P.cs[2]) { sc = P.cs[0] * Ld - P.cs[1]; if (sc < 0.001) sc = 0.001; }
+        else { bool ok = true; sc = P.cs[3] / jk_pow(Ld, P.cs[4], &ok); if (!ok) err |= JK_KERR_PB_MATH; }
+        jk_gamma_param gp;
+        {
+            const double alpha = n / 2;
+            if (alpha < 1.0) { err |= JK_KERR_PB_ALPHA; break; }
+            gp.a1 = alpha - 1.0 / 3.0; gp.a2 = 1.0 / jk_sqrt(9.0 * gp.a1); gp.beta = 1.0;
+        }
+        double passes = 2 * jk_gamma(gp, chi_st, rng);
+        const double thr = P.thr_tab[L < P.thr_cap ? (uint32_t)L : P.thr_cap];
+        while (passes > thr) passes = 2 * jk_gamma(gp, chi_st, rng);
+        passes *= sc;
+        passes += 1;
+        if (passes > P.max_passes_d) passes = P.max_passes_d;
+        const double wholes = __builtin_trunc(passes), fraction = passes - wholes;
+        double passes_left, passes_right, prop_left;
+        if ((((uint64_t)wholes) & 1ULL) == 0ULL) { prop_left = fraction; passes_left = __builtin_ceil(passes); passes_right = __builtin_floor(passes); }
+        else { prop_left = 1 - fraction; passes_left = __builtin_floor(passes); passes_right = __builtin_ceil(passes); }
+        const uint64_t split_pos = (uint64_t)__builtin_round(Ld * prop_left);
+
+        // ---- per-side error probabilities and qualities (update_probs, trunc_norm, fill_quals)
+        double cumL[3], cumR[3];
+        uint32_t qual_left = '!', qual_right = '!';
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const PassEntry pe = P.pass_tab[(uint32_t)(side == 0 ? passes_left : passes_right)];
+            double rnd;
+            if (pe.method == 0) {
+                jk_x87 c; c.m = pe.c_m; c.e = pe.c_e;
+                const double u = jk_runif_ab(rng(), jk_x87_from_double(pe.p), c);
+                rnd = jk_qnorm(u) * P.np1 + P.np0;
+            } else {
+                double u = jk_runif_double(rng());
+                double x_bar = jk_sqrt(pe.a_bar * pe.a_bar - 2 * jk_log(1 - u));
+                double v = jk_runif_double(rng());
+                while (v > (x_bar / pe.a_bar)) {
+                    u = jk_runif_double(rng());
+                    x_bar = jk_sqrt(pe.a_bar * pe.a_bar - 2 * jk_log(1 - u));
+                    v = jk_runif_double(rng());
+                }
+                rnd = P.np1 * x_bar + P.np0;
+            }
+            (side == 0 ? cumL : cumR)[0] = rnd;      // parked; the exponents need both draws first
+        }
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            double* cum = side == 0 ? cumL : cumR;
+            const PassEntry pe = P.pass_tab[(uint32_t)(side == 0 ? passes_left : passes_right)];
+            double expo = cum[0] * pe.sig + pe.sqrtv - P.sp1;
+            if (expo < 0.6) expo = 0.6;
+            bool ok = true;
+            cum[0] = jk_pow(P.prob_ins, expo, &ok);
+            cum[1] = jk_pow(P.prob_del, expo, &ok) + cum[0];
+            cum[2] = jk_pow(P.prob_subst, expo, &ok) + cum[1];
+            if (!ok) err |= JK_KERR_PB_MATH;
+            const double qv = __builtin_round(-10.0 * jk_log10(cum[2]));
+            // (uint64) of a negative value is undefined in the reference; x86-64 gives a huge number -> 93
+            const uint32_t q = (qv < 0 || qv > 93.0) ? 93u : (uint32_t)qv;
+            (side == 0 ? qual_left : qual_right) = q + 33u;
+        }
+        if (err) break;
+
+        // ---- pass 1: one draw per position (PacBioQualityError::sample, src/hts_pacbio.h:292-317)
+        uint64_t cur = 0, pos = 0, extra = chrom_len - L, n_ins = 0, n_del = 0;
+        {
+            const double* cum = cumL;
+            uint64_t word = 0;
+            while (cur < L) {
+                if (cur == split_pos) cum = cumR;
+                const double u = jk_runif_double(rng());
+                uint64_t type = 0;
+                if (u > cum[2]) {
+                    cur++;
+                } else if (u < cum[0]) {
+                    if (cur < L - 1) { type = 1; n_ins++; cur++; extra++; if (cur == split_pos) cum = cumR; }
+                    cur++;
+                } else if (u < cum[1]) {
+                    if (extra > 0) { type = 2; n_del++; extra--; }
+                } else {
+                    type = 3; cur++;
+                }
+                if (pos >= max_pos) { err |= JK_KERR_PB_TOO_LONG; break; }
+                word |= type << (2u * (pos & 31u));
+                pos++;
+                if ((pos & 31u) == 0) { evl[(pos >> 5) * ev_stride - ev_stride] = word; word = 0; }
+            }
+            if (pos & 31u) evl[(pos >> 5) * ev_stride] = word;
+        }
+        if (err) break;
+        uint64_t space = L + n_del - n_ins;
+        bool give_up = false;
+        if (!is_dup) {
+            if (space < chrom_len) read_start = jk_frag_start(rng(), chrom_len - space + 1);
+            else if (space == chrom_len) read_start = 0;
+            else { err |= JK_KERR_PB_SPACE; break; }
+        } else {
+            // duplicate: drop deletions from the back until the read fits (src/hts_pacbio.cpp:277-285)
+            uint64_t scan = pos;      // positions [0, pos) hold events
+            while (space + read_start > chrom_len && n_del > 0) {
+                while (scan > 0) {
+                    scan--;
+                    uint64_t* wp = evl + (scan >> 5) * ev_stride;
+                    const uint64_t wv = *wp;
+                    if (((wv >> (2u * (scan & 31u))) & 3u) == 2u) { *wp = wv & ~(3ULL << (2u * (scan & 31u))); break; }
+                }
+                n_del--; space--;
+            }
+            if (space + read_start > chrom_len) give_up = true;
+        }
+
+        if (!give_up) {
+            // ---- append_pool (src/hts_pacbio.cpp:350-414)
+            const bool reverse = jk_runif_lt_half(rng());
+            {
+                uint32_t hdr_len = P.g.hdr_off[ci + 1] - P.g.hdr_off[ci];
+                if ((uint64_t)o.pos + hdr_len + 24 + 2 * L + 8 > lane_cap) { err |= JK_KERR_POOL_OVERFLOW; break; }
+                for (uint32_t h = P.g.hdr_off[ci]; h < P.g.hdr_off[ci + 1]; h++) os_put(o, P.g.hdr_blob[h]);
+                uint64_t v = read_start, packed_lo = 0, packed_hi = 0; uint32_t nd = 0;
+                do {
+                    const uint64_t q = v / 10, d = v - q * 10;
+                    packed_hi = (packed_hi << 4) | (packed_lo >> 60);
+                    packed_lo = (packed_lo << 4) | d;
+                    v = q; nd++;
+                } while (v);
+                for (uint32_t d = 0; d < nd; d++) {
+                    os_put(o, '0' + (uint32_t)(packed_lo & 15u));
+                    packed_lo = (packed_lo >> 4) | (packed_hi << 60); packed_hi >>= 4;
+                }
+                os_put(o, '-');
+                os_put(o, reverse ? 'R' : 'F');
+                os_put(o, '\n');
+            }
+            // source walker: read[p] = forward chrom[start + p], reverse cmp(chrom[start + space - 1 - p])
+            const uint8_t* const gseq = P.g.seq;
+            const uint64_t chrom_off = P.g.chrom_off[HAP ? ci % P.g.n_chroms : ci];
+            uint64_t gaddr = 0, gbuf = 0; uint32_t gcnt = 0;
+            auto src_init = [&](uint64_t a0) {
+                const uint64_t ch = a0 & ~7ULL;
+                uint64_t v = *reinterpret_cast<const uint64_t*>(gseq + ch);
+                const uint32_t k = (uint32_t)a0 & 7u;
+                if (reverse) { v = __builtin_bswap64(v); gbuf = v >> (8u * (7u - k)); gcnt = k + 1; gaddr = ch - 8; }
+                else { gbuf = v >> (8u * k); gcnt = 8u - k; gaddr = ch + 8; }
+            };
+            auto src_next = [&]() -> uint32_t {
+                const uint32_t c = (uint32_t)gbuf & 0xffu;
+                gbuf >>= 8;
+                if (--gcnt == 0) {
+                    uint64_t v = *reinterpret_cast<const uint64_t*>(gseq + gaddr);
+                    if (reverse) { v = __builtin_bswap64(v); gaddr -= 8; } else gaddr += 8;
+                    gbuf = v; gcnt = 8;
+                }
+                return c;
+            };
+            uint64_t seg_end = ~0ULL;
+            int64_t mcur = -1;
+            auto seg_enter = [&](uint64_t p) {
+                const uint64_t hpos = reverse ? (read_start + space - 1 - p) : (read_start + p);
+                if (HAP) {
+                    const HapSeg sg = hap_resolve(P.h, chrom_off, ci, mcur, hpos);
+                    src_init(sg.addr);
+                    const uint64_t avail = reverse ? (hpos - sg.begin + 1) : (sg.end - hpos);
+                    seg_end = p + avail;
+                } else src_init(chrom_off + hpos);
+            };
+            if (HAP) mcur = hap_search(P.h, ci, reverse ? (read_start + space - 1) : read_start);
+            if (space > 0) seg_enter(0);
+
+            // ---- pass 2: emit bases
+            uint64_t cur2 = 0, p2 = 0, evw = 0;
+            while (cur2 < L) {
+                if ((p2 & 31u) == 0) evw = (p2 < pos) ? evl[(p2 >> 5) * ev_stride] : 0;
+                const uint32_t type = (p2 < pos) ? (uint32_t)(evw >> (2u * (p2 & 31u))) & 3u : 0u;
+                // the reference would read stale buffer bytes past the read's window here (only reachable when a
+                // read is as long as its chromosome); refuse instead of inventing bytes
+                if (p2 >= space) { err |= JK_KERR_PB_SPACE; break; }
+                if (HAP && p2 >= seg_end) seg_enter(p2);
+                const uint32_t c = src_next();
+                // character of read[p2] as the reference sees it (cmp_map for the reverse strand)
+                uint32_t ch, nt;
+                if (c < 4u) { nt = reverse ? (c ^ 2u) : c; ch = base_char(nt); }
+                else { nt = 4u; ch = reverse ? (c == 'N' ? 'N' : 0u) : c; }
+                if (type == 1u) {
+                    const uint32_t r4 = (uint32_t)jk_runif_index(rng(), 4);
+                    os_put(o, ch);
+                    os_put(o, r4 < 4u ? base_char(r4) : 0u);
+                    cur2 += 2;
+                } else if (type == 2u) {
+                    // deletion: nothing emitted
+                } else if (type == 3u) {
+                    const uint32_t m = runif_index32(rng(), 3);
+                    const uint32_t sub = (nt < 4u) ? ((m < 3u) ? base_char(m + (m >= nt ? 1u : 0u)) : 0u) : ((m < 3u) ? 'N' : 0u);
+                    os_put(o, sub);
+                    cur2++;
+                } else {
+                    os_put(o, ch);
+                    cur2++;
+                }
+                p2++;
+            }
+            if (err) break;
+            os_put(o, '\n'); os_put(o, '+'); os_put(o, '\n');
+            os_fill(o, qual_left, split_pos < L ? split_pos : L);
+            os_fill(o, qual_right, split_pos < L ? L - split_pos : 0);
+            os_put(o, '\n');
+        }
+        if (HAP) ccnt = ccnt > 0 ? ccnt - 1 : 0;     // n_reads_vc[hap][chr]-- (one_read) / if > 0 (re_read)
+
+        // ---- ReadWriterOneThread::create_reads tail (src/hts.h:263-278), one read end
+        made += 1; in_pool += 1;
+        const uint64_t xd = rng();
+        const bool dup = P.dup_all || xd < P.th_dup;
+        if (dup && made < quota && in_pool < P.pool_size) is_dup = true;
+        else { is_dup = false; if (in_pool >= P.pool_size || made >= quota) in_pool = 0; }
+    }
+    os_flush(o);
+    P.lane_bytes[lane] = o.pos;
+    if (o.pos > lane_cap) err |= JK_KERR_POOL_OVERFLOW;
+    P.lane_made[lane] = made;
+    if (err) atomicOr(P.err, err);
+}
+
+}  // namespace jk

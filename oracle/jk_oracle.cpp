@@ -34,6 +34,7 @@
 #include <stdexcept>
 #include <algorithm>
 #include <numeric>
+#include <cfloat>
 #include <memory>
 #include <omp.h>
 
@@ -723,6 +724,521 @@ static void give(const std::vector<char>& v, char** out, uint64_t* len) {
     if (!v.empty()) std::memcpy(*out, v.data(), v.size());
 }
 
+// -------------------------------------------------------------------------------------
+// R nmath pieces used by the PacBio path (src/hts_pacbio.h:178,349,352).  R is NOT under
+// /root/reference (DESCRIPTION:26 "R (>= 2.10)", unpinned) and is absent from this image: these are
+// restatements of the published algorithms R implements -- qnorm5: Wichura (1988) AS 241 PPND16;
+// pnorm5: Cody (1969) -- and their agreement with R itself is UNPINNED (checked numerically against
+// scipy in tests, not bit for bit).
+// -------------------------------------------------------------------------------------
+static double qnorm(double p) {
+    if (!(p > 0.0)) return -INFINITY;
+    if (!(p < 1.0)) return INFINITY;
+    const double q = p - 0.5;
+    double r, val;
+    if (std::fabs(q) <= 0.425) {
+        r = .180625 - q * q;
+        val = q * (((((((r * 2509.0809287301226727 + 33430.575583588128105) * r + 67265.770927008700853) * r
+                      + 45921.953931549871457) * r + 13731.693765509461125) * r + 1971.5909503065514427) * r
+                    + 133.14166789178437745) * r + 3.387132872796366608)
+              / (((((((r * 5226.495278852545925 + 28729.085735721942674) * r + 39307.89580009271061) * r
+                     + 21213.794301586595867) * r + 5394.1960214247511077) * r + 687.1870074920579083) * r
+                   + 42.313330701600911252) * r + 1.);
+        return val;
+    }
+    r = (q < 0) ? p : (0.5 - p + 0.5);
+    r = std::sqrt(-std::log(r));
+    if (r <= 5.) {
+        r += -1.6;
+        val = (((((((r * 7.7454501427834140764e-4 + .0227238449892691845833) * r + .24178072517745061177) * r
+                   + 1.27045825245236838258) * r + 3.64784832476320460504) * r + 5.7694972214606914055) * r
+                + 4.6303378461565452959) * r + 1.42343711074968357734)
+              / (((((((r * 1.05075007164441684324e-9 + 5.475938084995344946e-4) * r + .0151986665636164571966) * r
+                     + .14810397642748007459) * r + .68976733498510000455) * r + 1.6763848301838038494) * r
+                  + 2.05319162663775882187) * r + 1.);
+    } else {
+        r += -5.;
+        val = (((((((r * 2.01033439929228813265e-7 + 2.71155556874348757815e-5) * r + .0012426609473880784386) * r
+                   + .026532189526576123093) * r + .29656057182850489123) * r + 1.7848265399172913358) * r
+                + 5.4637849111641143699) * r + 6.6579046435011037772)
+              / (((((((r * 2.04426310338993978564e-15 + 1.4215117583164458887e-7) * r + 1.8463183175100546818e-5) * r
+                     + 7.868691311456132591e-4) * r + .0148753612908506148525) * r + .13692988092273580531) * r
+                  + .59983220655588793769) * r + 1.);
+    }
+    return (q < 0.0) ? -val : val;
+}
+
+// pnorm5(x, 0, 1, lower, !log) after Cody (1969) and qchisq(p, df) by Newton on the regularised incomplete
+// gamma function -- the same restatements the product's host set-up uses (jackalope_amd/csrc/jk_nmath.h);
+// they only produce per-run tables.  Parity with R's nmath is UNPINNED (see above).
+static double pnorm_std(double x) {          // P[N(0,1) <= x]
+    static const double a[5] = {2.2352520354606839287, 161.02823106855587881, 1067.6894854603709582,
+                                18154.981253343561249, 0.065682337918207449113};
+    static const double b[4] = {47.20258190468824187, 976.09855173777669322, 10260.932208618978205,
+                                45507.789335026729956};
+    static const double c[9] = {0.39894151208813466764, 8.8831497943883759412, 93.506656132177855979,
+                                597.27027639480026226, 2494.5375852903726711, 6848.1904505362823326,
+                                11602.651437647350124, 9842.7148383839780218, 1.0765576773720192317e-8};
+    static const double d[8] = {22.266688044328115691, 235.38790178262499861, 1519.377599407554805,
+                                6485.558298266760755, 18615.571640885098091, 34900.952721145977266,
+                                38912.003286093271411, 19685.429676859990727};
+    static const double p[6] = {0.21589853405795699, 0.1274011611602473639, 0.022235277870649807,
+                                0.001421619193227893466, 2.9112874951168792e-5, 0.02307344176494017303};
+    static const double q[5] = {1.28426009614491121, 0.468238212480865118, 0.0659881378689285515,
+                                0.00378239633202758244, 7.29751555083966205e-5};
+    const double eps = DBL_EPSILON * 0.5, y = std::fabs(x);
+    double xden, xnum, temp, del, xsq, cum, ccum;
+    if (std::isnan(x)) return x;
+    if (y <= 0.67448975) {
+        if (y > eps) {
+            xsq = x * x; xnum = a[4] * xsq; xden = xsq;
+            for (int i = 0; i < 3; ++i) { xnum = (xnum + a[i]) * xsq; xden = (xden + b[i]) * xsq; }
+        } else xnum = xden = 0.0;
+        temp = x * (xnum + a[3]) / (xden + b[3]);
+        return 0.5 + temp;
+    }
+    if (y <= 5.656854249492380195206754896838 /* sqrt(32) */) {
+        xnum = c[8] * y; xden = y;
+        for (int i = 0; i < 7; ++i) { xnum = (xnum + c[i]) * y; xden = (xden + d[i]) * y; }
+        temp = (xnum + c[7]) / (xden + d[7]);
+        xsq = std::trunc(y * 16) / 16; del = (y - xsq) * (y + xsq);
+        cum = std::exp(-xsq * xsq * 0.5) * std::exp(-del * 0.5) * temp; ccum = 1.0 - cum;
+        return x > 0. ? ccum : cum;
+    }
+    if (x > -37.5193 && x < 8.2924) {
+        xsq = 1.0 / (x * x);
+        xnum = p[5] * xsq; xden = xsq;
+        for (int i = 0; i < 4; ++i) { xnum = (xnum + p[i]) * xsq; xden = (xden + q[i]) * xsq; }
+        temp = xsq * (xnum + p[4]) / (xden + q[4]);
+        temp = (0.398942280401432677939946059934 /* 1/sqrt(2 pi) */ - temp) / y;
+        xsq = std::trunc(x * 16) / 16; del = (x - xsq) * (x + xsq);
+        cum = std::exp(-xsq * xsq * 0.5) * std::exp(-del * 0.5) * temp; ccum = 1.0 - cum;
+        return x > 0. ? ccum : cum;
+    }
+    return x > 0 ? 1.0 : 0.0;
+}
+
+// regularised lower incomplete gamma P(a, x), a > 0, x >= 0
+static long double gamma_p(long double a, long double x) {
+    if (x <= 0) return 0;
+    const long double lg = lgammal(a);
+    if (x < a + 1) {                                   // series
+        long double ap = a, del = 1 / a, sum = del;
+        for (int n = 0; n < 100000; n++) {
+            ap += 1; del *= x / ap; sum += del;
+            if (fabsl(del) < fabsl(sum) * 1e-20L) break;
+        }
+        return sum * expl(-x + a * logl(x) - lg);
+    }
+    const long double tiny = 1e-4000L;                 // Lentz continued fraction for Q(a, x)
+    long double bb = x + 1 - a, cc = 1 / tiny, dd = 1 / bb, h = dd;
+    for (int i = 1; i < 100000; i++) {
+        const long double an = -i * (i - a);
+        bb += 2;
+        dd = an * dd + bb; if (fabsl(dd) < tiny) dd = tiny;
+        cc = bb + an / cc; if (fabsl(cc) < tiny) cc = tiny;
+        dd = 1 / dd;
+        const long double dl = dd * cc;
+        h *= dl;
+        if (fabsl(dl - 1) < 1e-20L) break;
+    }
+    return 1 - expl(-x + a * logl(x) - lg) * h;
+}
+
+static double qchisq_upper_tail_point(double p, double df) {      // x with P[chi2_df <= x] = p
+    const long double a = 0.5L * df;
+    // Wilson-Hilferty start, then safeguarded Newton on P(a, x/2) - p
+    long double lo = 0, hi = 1;
+    while (gamma_p(a, hi / 2) < p) { lo = hi; hi *= 2; if (hi > 1e300L) return INFINITY; }
+    long double x = 0.5L * (lo + hi);
+    for (int it = 0; it < 200; it++) {
+        const long double f = gamma_p(a, x / 2) - p;
+        if (f > 0) hi = x; else lo = x;
+        // density of chi2_df at x
+        const long double dens = 0.5L * expl((a - 1) * logl(x / 2) - x / 2 - lgammal(a));
+        long double xn = x - f / dens;
+        if (!(xn > lo && xn < hi)) xn = 0.5L * (lo + hi);
+        if (fabsl(xn - x) <= 1e-18L * fabsl(x)) { x = xn; break; }
+        x = xn;
+    }
+    return static_cast<double>(x);
+}
+
+
+// -------------------------------------------------------------------------------------
+// PacBio samplers (src/hts_pacbio.h:45-398, src/hts_pacbio.cpp:27-131)
+// -------------------------------------------------------------------------------------
+struct PacBioParams {
+    double scale, sigma, loc, min_read_len;
+    std::vector<double> read_probs; std::vector<u64> read_lens;
+    u64 max_passes;
+    std::vector<double> chi2_params_n, chi2_params_s, sqrt_params, norm_params;
+    double prob_thresh, prob_ins, prob_del, prob_subst;
+};
+
+struct PacBioReadLenSampler {
+    std::vector<u64> read_lens; Alias sampler; std::lognormal_distribution<double> distr;
+    bool use_distr; double min_read_len, loc;
+    PacBioReadLenSampler() : use_distr(true), min_read_len(1), loc(0) {}
+    explicit PacBioReadLenSampler(const PacBioParams& p) {
+        if (p.read_probs.empty()) {
+            distr = std::lognormal_distribution<double>(std::log(p.scale), p.sigma);
+            use_distr = true; min_read_len = std::ceil(p.min_read_len); loc = p.loc;
+            if (min_read_len < 1) min_read_len = 1;
+        } else {
+            if (p.read_probs.size() != p.read_lens.size()) throw std::runtime_error("Probability and read lengths vector should be the same length.");
+            read_lens = p.read_lens; sampler = Alias(p.read_probs); use_distr = false; min_read_len = 0; loc = 0;
+        }
+    }
+    u64 sample(Pcg64& eng) {       // src/hts_pacbio.cpp:27-45
+        u64 len_;
+        if (use_distr) {
+            double rnd = distr(eng) + loc;
+            u64 iters = 0;
+            while (rnd < min_read_len && iters < 10) { rnd = distr(eng) + loc; iters++; }
+            if (rnd < min_read_len) rnd = min_read_len;
+            len_ = static_cast<u64>(rnd);
+        } else {
+            u64 ind = sampler.sample(eng);
+            len_ = read_lens[ind];
+        }
+        return len_;
+    }
+};
+
+struct PacBioPassSampler {     // src/hts_pacbio.h:116-205
+    u64 max_passes; std::vector<double> chi2_params_n, chi2_params_s;
+    std::chi_squared_distribution<double> distr = std::chi_squared_distribution<double>(1);
+    void sample(u64& split_pos, double& passes_left, double& passes_right, Pcg64& eng, const double& read_length) {
+        double passes, prop_left;
+        double n = chi2_params_n[0] * std::min(read_length, chi2_params_n[2]) + chi2_params_n[1];
+        if (n < 0.001) n = 0.001;
+        double s;
+        if (read_length <= chi2_params_s[2]) {
+            s = chi2_params_s[0] * read_length - chi2_params_s[1];
+            if (s < 0.001) s = 0.001;
+        } else s = chi2_params_s[3] / std::pow(read_length, chi2_params_s[4]);
+        distr.param(std::chi_squared_distribution<double>::param_type(n));
+        passes = distr(eng);
+        double outlier_threshold = qchisq_upper_tail_point(0.9925, n);     // R::qchisq(0.9925, n, 1, 0)
+        while (passes > outlier_threshold) passes = distr(eng);
+        passes *= s;
+        passes += 1;
+        if (passes > max_passes) passes = max_passes;
+        double fraction, wholes;
+        fraction = std::modf(passes, &wholes);
+        if ((static_cast<u64>(wholes) & 1ULL) == 0ULL) {
+            prop_left = fraction;
+            split_pos = std::round(static_cast<double>(read_length) * prop_left);
+            passes_left = std::ceil(passes); passes_right = std::floor(passes);
+        } else {
+            prop_left = 1 - fraction;
+            split_pos = std::round(static_cast<double>(read_length) * prop_left);
+            passes_left = std::floor(passes); passes_right = std::ceil(passes);
+        }
+    }
+};
+
+static inline long double runif_ab(Pcg64& eng, const long double& a, const long double& b) {   // src/pcg.h:103-105
+    return a + ((static_cast<long double>(eng()) + 1) / (MAX64 + 2)) * (b - a);
+}
+
+struct PacBioQualityError {    // src/hts_pacbio.h:213-398, src/hts_pacbio.cpp:50-131
+    std::vector<double> sqrt_params, norm_params;
+    double prob_thresh, prob_ins, prob_del, prob_subst, min_exp;
+    std::vector<double> cum_probs_left = std::vector<double>(3), cum_probs_right = std::vector<double>(3);
+    PacBioQualityError() {}
+    explicit PacBioQualityError(const PacBioParams& p)
+        : sqrt_params(p.sqrt_params), norm_params(p.norm_params), prob_thresh(p.prob_thresh), prob_ins(p.prob_ins),
+          prob_del(p.prob_del), prob_subst(p.prob_subst), min_exp(calc_min_exp()) {}
+    double calc_min_exp() {
+        double min_exp_ = 1;
+        double total = std::pow(prob_ins, min_exp_) + std::pow(prob_del, min_exp_) + std::pow(prob_subst, min_exp_);
+        double left, right;
+        if (total < prob_thresh) {
+            while (total < prob_thresh) {
+                min_exp_ /= 2;
+                total = std::pow(prob_ins, min_exp_) + std::pow(prob_del, min_exp_) + std::pow(prob_subst, min_exp_);
+            }
+            left = min_exp_; right = min_exp_ * 2;
+        } else {
+            while (total > prob_thresh) {
+                min_exp_ *= 2;
+                total = std::pow(prob_ins, min_exp_) + std::pow(prob_del, min_exp_) + std::pow(prob_subst, min_exp_);
+            }
+            left = min_exp_ / 2; right = min_exp_;
+        }
+        for (u64 i = 0; i < 15; i++) {
+            double m = (left + right) / 2;
+            total = std::pow(prob_ins, m) + std::pow(prob_del, m) + std::pow(prob_subst, m);
+            if (total == prob_thresh) { min_exp_ = m; break; }
+            else if (total > prob_thresh) { left = m; min_exp_ = (m + right) / 2; }
+            else { right = m; min_exp_ = (left + m) / 2; }
+        }
+        return min_exp_;
+    }
+    inline double sigmoid(const double& x) { return 1 / (1 + std::pow(2, (-2.5 / 3 * x + 6.5 / 3))); }
+    double trunc_norm(const double& lower_thresh, Pcg64& eng) {
+        double rnd;
+        double a_bar = (lower_thresh - norm_params[0]) / norm_params[1];
+        if (lower_thresh < (norm_params[0] + 5 * norm_params[1])) {
+            double p = pnorm_std(a_bar);            // R::pnorm5(a_bar, 0, 1, 1, 0)
+            double u = runif_ab(eng, p, 1);
+            double x = qnorm(u);                    // R::qnorm5(u, 0, 1, 1, 0)
+            rnd = x * norm_params[1] + norm_params[0];
+        } else {
+            double u, x_bar, v;
+            u = runif_01(eng);
+            x_bar = std::sqrt(a_bar * a_bar - 2 * std::log(1 - u));
+            v = runif_01(eng);
+            while (v > (x_bar / a_bar)) {
+                u = runif_01(eng);
+                x_bar = std::sqrt(a_bar * a_bar - 2 * std::log(1 - u));
+                v = runif_01(eng);
+            }
+            rnd = norm_params[1] * x_bar + norm_params[0];
+        }
+        return rnd;
+    }
+    void update_probs(Pcg64& eng, const double& passes_left, const double& passes_right) {
+        double left_thresh = (min_exp - (std::sqrt(passes_left + sqrt_params[0]) - sqrt_params[1])) / sigmoid(passes_left);
+        double right_thresh = (min_exp - (std::sqrt(passes_right + sqrt_params[0]) - sqrt_params[1])) / sigmoid(passes_right);
+        double incr_quals_l = trunc_norm(left_thresh, eng);
+        double incr_quals_r = trunc_norm(right_thresh, eng);
+        double exponent_left = incr_quals_l * sigmoid(passes_left) + std::sqrt(passes_left + sqrt_params[0]) - sqrt_params[1];
+        double exponent_right = incr_quals_r * sigmoid(passes_right) + std::sqrt(passes_right + sqrt_params[0]) - sqrt_params[1];
+        if (exponent_left < 0.6) exponent_left = 0.6;
+        if (exponent_right < 0.6) exponent_right = 0.6;
+        cum_probs_left[0] = std::pow(prob_ins, exponent_left);
+        cum_probs_left[1] = std::pow(prob_del, exponent_left) + cum_probs_left[0];
+        cum_probs_left[2] = std::pow(prob_subst, exponent_left) + cum_probs_left[1];
+        cum_probs_right[0] = std::pow(prob_ins, exponent_right);
+        cum_probs_right[1] = std::pow(prob_del, exponent_right) + cum_probs_right[0];
+        cum_probs_right[2] = std::pow(prob_subst, exponent_right) + cum_probs_right[1];
+    }
+    void fill_quals(char& qual_left, char& qual_right) {
+        const u64 max_qual = 93, qual_start = static_cast<u64>('!');
+        u64 tmp_l = std::round(-10.0 * std::log10(cum_probs_left.back()));
+        u64 tmp_r = std::round(-10.0 * std::log10(cum_probs_right.back()));
+        if (tmp_l > max_qual) tmp_l = max_qual;
+        if (tmp_r > max_qual) tmp_r = max_qual;
+        qual_left = static_cast<char>(tmp_l + qual_start);
+        qual_right = static_cast<char>(tmp_r + qual_start);
+    }
+    void sample(Pcg64& eng, char& qual_left, char& qual_right, std::deque<u64>& insertions, std::deque<u64>& deletions,
+                std::deque<u64>& substitutions, const u64& chrom_len, const u64& read_length, const u64& split_pos,
+                const double& passes_left, const double& passes_right) {
+        insertions.clear(); deletions.clear(); substitutions.clear();
+        update_probs(eng, passes_left, passes_right);
+        fill_quals(qual_left, qual_right);
+        u64 current_length = 0, chrom_pos = 0;
+        u64 extra_space = chrom_len - read_length;
+        double u;
+        std::vector<double>* cum_probs = &cum_probs_left;
+        while (current_length < read_length) {
+            if (current_length == split_pos) cum_probs = &cum_probs_right;
+            u = runif_01(eng);
+            if (u > cum_probs->at(2)) {
+                current_length++;
+            } else if (u < cum_probs->at(0)) {
+                if (current_length < (read_length - 1)) {
+                    insertions.push_back(chrom_pos);
+                    current_length++;
+                    extra_space++;
+                    if (current_length == split_pos) cum_probs = &cum_probs_right;
+                }
+                current_length++;
+            } else if (u < cum_probs->at(1)) {
+                if (extra_space > 0) { deletions.push_back(chrom_pos); extra_space--; }
+            } else {
+                substitutions.push_back(chrom_pos);
+                current_length++;
+            }
+            chrom_pos++;
+        }
+    }
+};
+
+// PacBioOneGenome<T> (src/hts_pacbio.h:420-560, src/hts_pacbio.cpp:136-485).  The copy made per thread
+// copies the samplers and quotas only; the read buffer and event deques start fresh (the reference's copy
+// constructor does not copy them).
+struct PacBioOneGenome {
+    PacBioReadLenSampler len_sampler; PacBioPassSampler pass_sampler; PacBioQualityError qe_sampler;
+    std::vector<u64> chrom_reads;
+    const Genome* genome;
+    u64 split_pos = 0; double passes_left = 0, passes_right = 0;
+    char qual_left = '!', qual_right = '!';
+    u64 read_chrom_space = 1;
+    std::string read = std::string(1000, 'N');
+    std::deque<u64> insertions, deletions, substitutions;
+    u64 chrom_ind = 0, read_length = 0, read_start = 0;
+
+    PacBioOneGenome(const Genome& g, const PacBioParams& p) : len_sampler(p), qe_sampler(p), genome(&g) {
+        pass_sampler.max_passes = p.max_passes; pass_sampler.chi2_params_n = p.chi2_params_n; pass_sampler.chi2_params_s = p.chi2_params_s;
+    }
+    PacBioOneGenome(const PacBioOneGenome& o)
+        : len_sampler(o.len_sampler), pass_sampler(o.pass_sampler), qe_sampler(o.qe_sampler), chrom_reads(o.chrom_reads), genome(o.genome) {}
+    void reset_quota() { chrom_reads.clear(); }
+    void add_n_reads(u64 n_reads, SeedSource& seeds) {
+        std::vector<double> probs_(genome->chrom_sizes.begin(), genome->chrom_sizes.end());
+        chrom_reads = reads_per_group(n_reads, probs_, seeds);
+    }
+    void sample_read_info(u64 chrom_len, Pcg64& eng) {     // shared middle of one_read (both overloads)
+        read_length = len_sampler.sample(eng);
+        if (read_length >= chrom_len) read_length = chrom_len;
+        pass_sampler.sample(split_pos, passes_left, passes_right, eng, read_length);
+        qe_sampler.sample(eng, qual_left, qual_right, insertions, deletions, substitutions, chrom_len, read_length,
+                          split_pos, passes_left, passes_right);
+        read_chrom_space = read_length + deletions.size() - insertions.size();
+        if (read_chrom_space < chrom_len) {
+            double u = runif_01(eng);
+            read_start = static_cast<u64>(u * (chrom_len - read_chrom_space + 1));
+        } else if (read_chrom_space == chrom_len) read_start = 0;
+        else throw std::runtime_error("read_chrom_space should never exceed the chromosome length.");
+    }
+    bool resample_for_duplicate(u64 chrom_len, Pcg64& eng) {   // shared middle of re_read; false = give up
+        pass_sampler.sample(split_pos, passes_left, passes_right, eng, read_length);
+        qe_sampler.sample(eng, qual_left, qual_right, insertions, deletions, substitutions, chrom_len, read_length,
+                          split_pos, passes_left, passes_right);
+        read_chrom_space = read_length + deletions.size() - insertions.size();
+        while ((read_chrom_space + read_start) > chrom_len) {
+            if (deletions.empty()) break;
+            deletions.pop_back();
+            read_chrom_space--;
+        }
+        return !((read_chrom_space + read_start) > chrom_len);
+    }
+    // src/hts_pacbio.cpp:350-414 / :417-485
+    void append_pool(const std::string& chrom, std::vector<char>& pool, Pcg64& eng) {
+        bool reverse = runif_01(eng) < 0.5;
+        pool.push_back('@');
+        for (char c : genome->name) pool.push_back(c);
+        pool.push_back('-');
+        for (char c : genome->chrom_names[chrom_ind]) pool.push_back(c);
+        pool.push_back('-');
+        for (char c : std::to_string(read_start)) pool.push_back(c);
+        pool.push_back('-');
+        pool.push_back(reverse ? 'R' : 'F');
+        pool.push_back('\n');
+        fill_read(chrom, read, 0, read_start, read_chrom_space);
+        if (reverse) rev_comp_n(read, read_chrom_space);
+        u64 read_pos = 0, current_length = 0, rndi;
+        while (current_length < read_length) {
+            if (!insertions.empty() && read_pos == insertions.front()) {
+                rndi = static_cast<u64>(runif_01(eng) * 4);
+                pool.push_back(read[read_pos]);
+                pool.push_back(BASES[rndi]);
+                insertions.pop_front();
+                current_length += 2;
+            } else if (!deletions.empty() && read_pos == deletions.front()) {
+                deletions.pop_front();
+            } else if (!substitutions.empty() && read_pos == substitutions.front()) {
+                rndi = static_cast<u64>(runif_01(eng) * 3);
+                pool.push_back(MM_NUCLEOS[nt_index(read[read_pos])][rndi]);
+                substitutions.pop_front();
+                current_length++;
+            } else {
+                pool.push_back(read[read_pos]);
+                current_length++;
+            }
+            read_pos++;
+        }
+        pool.push_back('\n'); pool.push_back('+'); pool.push_back('\n');
+        for (u64 i = 0; i < split_pos; i++) pool.push_back(qual_left);
+        for (u64 i = split_pos; i < read_length; i++) pool.push_back(qual_right);
+        pool.push_back('\n');
+    }
+    void one_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
+        chrom_ind = 0;
+        while (chrom_ind < chrom_reads.size() && chrom_reads[chrom_ind] == 0) chrom_ind++;
+        if (chrom_ind == chrom_reads.size()) { finished = true; return; }
+        sample_read_info(genome->chrom_sizes[chrom_ind], eng);
+        append_pool(*genome->chroms[chrom_ind], pools[0], eng);
+        // NB: the reference never decrements chrom_reads on this path (src/hts_pacbio.cpp:136-188 only reads
+        // it, :147), so every read of a thread comes from its first chromosome with a non-zero quota.
+    }
+    void re_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
+        (void)finished;
+        if (!resample_for_duplicate(genome->chrom_sizes[chrom_ind], eng)) return;
+        append_pool(*genome->chroms[chrom_ind], pools[0], eng);
+    }
+    void one_read_str(const std::string& chrom, u64 chrom_i, std::vector<std::vector<char>>& pools, Pcg64& eng) {
+        chrom_ind = chrom_i;
+        sample_read_info(genome->chrom_sizes[chrom_ind], eng);
+        append_pool(chrom, pools[0], eng);
+    }
+    void re_read_str(const std::string& chrom, u64 chrom_i, std::vector<std::vector<char>>& pools, Pcg64& eng) {
+        chrom_ind = chrom_i;
+        if (!resample_for_duplicate(genome->chrom_sizes[chrom_ind], eng)) return;
+        append_pool(chrom, pools[0], eng);
+    }
+};
+
+// PacBioHaplotypes (src/hts_pacbio.h:569-715, src/hts_pacbio.cpp:488-551)
+struct PacBioHaplotypes {
+    const std::vector<HapGenome>* haps;
+    std::vector<Genome> genomes;
+    std::vector<std::vector<u64>> n_reads_vc;
+    std::vector<PacBioOneGenome> read_makers;
+    std::vector<double> hap_probs;
+    u64 hap, chr;
+    std::string hap_chrom_seq;
+    PacBioHaplotypes(const std::vector<HapGenome>& hs, const std::vector<double>& probs, const PacBioParams& p)
+        : haps(&hs), hap_probs(probs), hap(0), chr(0) {
+        genomes.resize(hs.size());
+        for (u64 i = 0; i < hs.size(); i++) {
+            genomes[i].name = hs[i].name;
+            for (const HapChrom& hc : hs[i].chroms) {
+                genomes[i].chrom_names.push_back(hc.name);
+                genomes[i].chroms.push_back(nullptr);
+                genomes[i].chrom_sizes.push_back(hc.chrom_size);
+            }
+        }
+        read_makers.reserve(hs.size());
+        for (u64 i = 0; i < hs.size(); i++) read_makers.push_back(PacBioOneGenome(genomes[i], p));
+    }
+    PacBioHaplotypes(const PacBioHaplotypes& o)
+        : haps(o.haps), genomes(o.genomes), n_reads_vc(o.n_reads_vc), read_makers(o.read_makers), hap_probs(o.hap_probs),
+          hap(o.hap), chr(o.chr), hap_chrom_seq(o.hap_chrom_seq) {
+        for (u64 i = 0; i < read_makers.size(); i++) read_makers[i].genome = &genomes[i];
+    }
+    void reset_quota() { n_reads_vc.clear(); for (auto& rm : read_makers) rm.reset_quota(); }
+    void add_n_reads(u64 n_reads, SeedSource& seeds) {
+        u64 n_haps = haps->size();
+        std::vector<u64> hap_reads = reads_per_group(n_reads, hap_probs, seeds);
+        for (u64 v = 0; v < n_haps; v++) {
+            std::vector<double> chrom_probs;
+            for (const HapChrom& vc : (*haps)[v].chroms) chrom_probs.push_back(vc.chrom_size);
+            n_reads_vc.push_back(reads_per_group(hap_reads[v], chrom_probs, seeds));
+        }
+        for (u64 i = 0; i < n_haps; i++) read_makers[i].add_n_reads(hap_reads[i], seeds);
+    }
+    void one_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
+        if (hap == haps->size()) { finished = true; return; }
+        if (n_reads_vc[hap][chr] == 0 || hap_chrom_seq.empty()) {
+            u64 new_hap = hap, new_chr = chr;
+            for (; new_hap < n_reads_vc.size(); new_hap++) {
+                while (n_reads_vc[new_hap][new_chr] == 0) {
+                    new_chr++;
+                    if (new_chr == n_reads_vc[new_hap].size()) break;
+                }
+                if (new_chr < n_reads_vc[new_hap].size()) break;
+                else new_chr = 0;
+            }
+            hap = new_hap; chr = new_chr;
+            if (hap == haps->size()) { finished = true; return; }
+            hap_chrom_seq = (*haps)[hap].chroms[chr].get_chrom_full();
+        }
+        read_makers[hap].one_read_str(hap_chrom_seq, chr, pools, eng);
+        n_reads_vc[hap][chr]--;
+    }
+    void re_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
+        if (hap == haps->size()) { finished = true; return; }
+        read_makers[hap].re_read_str(hap_chrom_seq, chr, pools, eng);
+        if (n_reads_vc[hap][chr] > 0) n_reads_vc[hap][chr]--;
+    }
+};
+
 static thread_local std::string g_err;
 
 }  // namespace orc
@@ -773,6 +1289,14 @@ void orc_eval_many(int what, const uint64_t* in, uint64_t n, uint64_t aux, uint6
             case 6: out[i] = orc_frag_start(in[i], aux); break;
             case 7: out[i] = bits(std::log(dbl(in[i]))); break;
             case 8: out[i] = bits(std::sqrt(dbl(in[i]))); break;
+            case 10: out[i] = bits(std::exp(dbl(in[i]))); break;
+            case 11: out[i] = bits(std::pow(dbl(in[2 * i]), dbl(in[2 * i + 1]))); break;
+            case 12: out[i] = bits(std::log10(dbl(in[i]))); break;
+            case 13: out[i] = bits(orc::qnorm(dbl(in[i]))); break;
+            case 14: {   // (double) runif_ab(eng, a, 1): a + runif_01 * (b - a) in long double (src/pcg.h:103-105)
+                const long double a = dbl(in[4 * i + 1]), b = 1.0L;
+                const double u = a + runif_01_from(in[4 * i]) * (b - a);
+                out[i] = bits(u); break; }
             default: break;
         }
     }
@@ -946,5 +1470,82 @@ int orc_illumina_hap(const orc_hap_set* hs, const double* hap_probs, const orc_i
         return 0;
     } catch (std::exception& e) { g_err = e.what(); return 1; }
 }
+
+}  // extern "C" (reopened below)
+
+struct orc_pacbio_args {
+    uint64_t n_reads, n_threads, read_pool_size;
+    double prob_dup;
+    double scale, sigma, loc, min_read_len;
+    const double* read_probs; const uint64_t* read_lens; uint64_t n_read_lens;
+    uint64_t max_passes;
+    const double* chi2_params_n;   // [3]
+    const double* chi2_params_s;   // [5]
+    const double* sqrt_params;     // [2]
+    const double* norm_params;     // [2]
+    double prob_thresh, prob_ins, prob_del, prob_subst;
+    const uint32_t* seed_words; uint64_t n_seed_words;
+    uint64_t thread_begin, thread_end; int32_t discard;
+    uint64_t* thread_bytes;
+};
+
+static PacBioParams to_pb_params(const orc_pacbio_args* a) {
+    PacBioParams p;
+    p.scale = a->scale; p.sigma = a->sigma; p.loc = a->loc; p.min_read_len = a->min_read_len;
+    if (a->n_read_lens) { p.read_probs.assign(a->read_probs, a->read_probs + a->n_read_lens); p.read_lens.assign(a->read_lens, a->read_lens + a->n_read_lens); }
+    p.max_passes = a->max_passes;
+    p.chi2_params_n.assign(a->chi2_params_n, a->chi2_params_n + 3);
+    p.chi2_params_s.assign(a->chi2_params_s, a->chi2_params_s + 5);
+    p.sqrt_params.assign(a->sqrt_params, a->sqrt_params + 2);
+    p.norm_params.assign(a->norm_params, a->norm_params + 2);
+    p.prob_thresh = a->prob_thresh; p.prob_ins = a->prob_ins; p.prob_del = a->prob_del; p.prob_subst = a->prob_subst;
+    return p;
+}
+
+template <typename Filler>
+static void run_pacbio(const Filler& base, const orc_pacbio_args* a, char** out, uint64_t* len, uint64_t* used) {
+    SeedSource seeds{a->seed_words, a->n_seed_words, 0};
+    std::vector<std::vector<char>> files;
+    RunOpts opts; opts.thread_begin = a->thread_begin; opts.thread_end = a->thread_end; opts.discard = a->discard != 0;
+    run_threads(base, a->n_reads, a->prob_dup, a->read_pool_size, 1, a->n_threads, seeds, files, opts);
+    if (a->thread_bytes) for (u64 t = 0; t < a->n_threads; t++) a->thread_bytes[t] = opts.thread_bytes[0][t];
+    give(files[0], out, len);
+    if (used) *used = seeds.pos;
+}
+
+extern "C" {
+
+// pacbio_ref_cpp (src/hts_pacbio.cpp:579-640), uncompressed sink in memory
+int orc_pacbio_ref(uint64_t n_chroms, const char* const* chrom_names, const char* const* chrom_seqs,
+                   const uint64_t* chrom_lens, const orc_pacbio_args* a, char** out, uint64_t* len, uint64_t* seed_words_used) {
+    try {
+        std::vector<std::string> seqs(n_chroms);
+        Genome g; g.name = "REF";
+        for (uint64_t i = 0; i < n_chroms; i++) {
+            seqs[i].assign(chrom_seqs[i], chrom_lens[i]);
+            g.chrom_names.push_back(chrom_names[i]);
+            g.chrom_sizes.push_back(chrom_lens[i]);
+        }
+        for (uint64_t i = 0; i < n_chroms; i++) g.chroms.push_back(&seqs[i]);
+        PacBioOneGenome base(g, to_pb_params(a));
+        run_pacbio(base, a, out, len, seed_words_used);
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// pacbio_hap_cpp (src/hts_pacbio.cpp:646-715), sep_files = FALSE
+int orc_pacbio_hap(const orc_hap_set* hs, const double* hap_probs, const orc_pacbio_args* a,
+                   char** out, uint64_t* len, uint64_t* seed_words_used) {
+    try {
+        std::vector<std::string> refs; std::vector<HapGenome> haps;
+        build_haps(hs, refs, haps);
+        PacBioHaplotypes base(haps, std::vector<double>(hap_probs, hap_probs + hs->n_haps), to_pb_params(a));
+        run_pacbio(base, a, out, len, seed_words_used);
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+double orc_pnorm(double x) { return pnorm_std(x); }
+double orc_qchisq(double p, double df) { return qchisq_upper_tail_point(p, df); }
 
 }  // extern "C"

@@ -225,3 +225,84 @@ def illumina_hap(hs, *, hap_probs, paired, matepair=False, n_reads, prob_dup, n_
     r1 = _take(o1, l1.value)
     r2 = _take(o2, l2.value) if paired else None
     return r1, r2, used.value
+
+
+class OrcPacbioArgs(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_threads", C.c_uint64), ("read_pool_size", C.c_uint64),
+                ("prob_dup", C.c_double),
+                ("scale", C.c_double), ("sigma", C.c_double), ("loc", C.c_double), ("min_read_len", C.c_double),
+                ("read_probs", C.c_void_p), ("read_lens", C.c_void_p), ("n_read_lens", C.c_uint64),
+                ("max_passes", C.c_uint64),
+                ("chi2_params_n", C.c_void_p), ("chi2_params_s", C.c_void_p), ("sqrt_params", C.c_void_p),
+                ("norm_params", C.c_void_p),
+                ("prob_thresh", C.c_double), ("prob_ins", C.c_double), ("prob_del", C.c_double), ("prob_subst", C.c_double),
+                ("seed_words", C.c_void_p), ("n_seed_words", C.c_uint64),
+                ("thread_begin", C.c_uint64), ("thread_end", C.c_uint64), ("discard", C.c_int32),
+                ("thread_bytes", C.c_void_p)]
+
+
+PACBIO_DEFAULTS = dict(chi2_params_s=(0.01214, -5.12, 675, 48303.0732881, 1.4691051212330266),
+                       chi2_params_n=(0.00189237136, 2.53944970, 5500), max_passes=40, sqrt_params=(0.5, 0.2247),
+                       norm_params=(0, 0.2), prob_thresh=0.2, ins_prob=0.11, del_prob=0.04, sub_prob=0.01,
+                       min_read_length=50, lognorm_read_length=(0.200110276521, -10075.4363813, 17922.611306),
+                       custom_read_lengths=None, prob_dup=0.0, read_pool_size=100)
+
+
+def _pb_args(pb, n_reads, n_threads, words, thread_begin=0, thread_end=0, discard=False):
+    d = dict(PACBIO_DEFAULTS)
+    d.update(pb)
+    a = OrcPacbioArgs()
+    keep = []
+    a.n_reads, a.n_threads, a.read_pool_size, a.prob_dup = int(n_reads), int(n_threads), int(d["read_pool_size"]), float(d["prob_dup"])
+    a.sigma, a.loc, a.scale = [float(x) for x in d["lognorm_read_length"]]
+    a.min_read_len = float(d["min_read_length"])
+    if d["custom_read_lengths"] is not None:
+        crl = np.asarray(d["custom_read_lengths"], dtype=np.float64)
+        if crl.ndim == 2:
+            lens, probs = crl[:, 0], crl[:, 1]
+        else:
+            lens, probs = crl, np.ones(crl.size)
+        lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        probs = np.ascontiguousarray(probs, dtype=np.float64)
+        keep += [lens, probs]
+        a.read_probs, a.read_lens, a.n_read_lens = probs.ctypes.data, lens.ctypes.data, lens.size
+    a.max_passes = int(d["max_passes"])
+    for name, key in (("chi2_params_n", "chi2_params_n"), ("chi2_params_s", "chi2_params_s"),
+                      ("sqrt_params", "sqrt_params"), ("norm_params", "norm_params")):
+        arr = np.ascontiguousarray(d[key], dtype=np.float64)
+        keep.append(arr)
+        setattr(a, name, arr.ctypes.data)
+    a.prob_thresh, a.prob_ins, a.prob_del, a.prob_subst = float(d["prob_thresh"]), float(d["ins_prob"]), float(d["del_prob"]), float(d["sub_prob"])
+    words = np.ascontiguousarray(words, dtype=np.uint32)
+    keep.append(words)
+    a.seed_words, a.n_seed_words = words.ctypes.data, words.size
+    a.thread_begin, a.thread_end, a.discard = int(thread_begin), int(thread_end), int(bool(discard))
+    tb = np.zeros(int(n_threads), dtype=np.uint64)
+    keep.append(tb)
+    a.thread_bytes = tb.ctypes.data
+    return a, keep, tb
+
+
+def pacbio_ref(genome, pb, *, n_reads, n_threads, words, **kw):
+    """Oracle run of pacbio_ref_cpp.  `pb` overrides PACBIO_DEFAULTS (names as in R's pacbio())."""
+    a, keep, tb = _pb_args(pb, n_reads, n_threads, words, **kw)
+    n = genome.n_chroms()
+    names = (C.c_char_p * n)(*[x.encode() for x in genome.names])
+    seqs = (C.c_void_p * n)(*[s.ctypes.data for s in genome.seqs])
+    lens = (C.c_uint64 * n)(*genome.sizes())
+    o, ln, used = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    rc = lib().orc_pacbio_ref(C.c_uint64(n), names, seqs, lens, C.byref(a), C.byref(o), C.byref(ln), C.byref(used))
+    if rc != 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+    return _take(o, ln.value), used.value, tb
+
+
+def pacbio_hap(hs, pb, *, hap_probs, n_reads, n_threads, words, **kw):
+    a, keep, tb = _pb_args(pb, n_reads, n_threads, words, **kw)
+    v, keep2 = _hap_view(hs)
+    hp = np.ascontiguousarray(hap_probs, dtype=np.float64)
+    o, ln, used = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    rc = lib().orc_pacbio_hap(C.byref(v), hp.ctypes.data_as(C.c_void_p), C.byref(a), C.byref(o), C.byref(ln), C.byref(used))
+    if rc != 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+    return _take(o, ln.value), used.value, tb

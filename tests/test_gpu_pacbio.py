@@ -1,0 +1,97 @@
+"""GPU parity for pacbio() (pacbio_ref_cpp / pacbio_hap_cpp, src/hts_pacbio.cpp:579-715) against the CPU
+oracle on the same seeded inputs: FASTQ bytes must be identical.  The reference's own PacBio tests are
+structural only (tests/testthat/test-sequencer.R:285-319); they are restated here too."""
+import numpy as np
+import pytest
+
+from helpers import first_diff, fastq_records
+from jackalope_amd.genome import random_haplotypes
+
+pytestmark = pytest.mark.gpu
+
+
+def hip(ja, obj, n_reads, T, words, pb, **extra):
+    s = ja.pacbio(obj, None, n_reads, n_threads=T, seed_words=words, _session=True, **pb, **extra)
+    with s:
+        s.generate()
+        sizes, reads = s.sizes()
+        return s.fetch(0), reads, s.seed_words_used()
+
+
+def check_ref(ja, O, g, n_reads, T, pb=None, seed=1):
+    pb = pb or {}
+    words = ja.seed_words(seed, 16 * T + 64)
+    o, used_o, _ = O.pacbio_ref(g, pb, n_reads=n_reads, n_threads=T, words=words)
+    h, reads, used_h = hip(ja, g, n_reads, T, words, pb)
+    assert used_o == used_h
+    if h != o:
+        raise AssertionError("FASTQ differs at byte %d:\nHIP    %r\noracle %r" % first_diff(h, o))
+    assert reads == n_reads
+    return h
+
+
+def test_reference_structural_checks(ja, O):
+    """test-sequencer.R:285-300: 4 lines per read, '@' ids, '+' separators, equal base/quality lengths."""
+    g = ja.synthetic_genome([400_000, 90_000], seed=41)
+    h = check_ref(ja, O, g, 100, 1)
+    recs = fastq_records(h)
+    assert len(recs) == 100
+    assert all(r[0].startswith(b"@REF-chrom0-") and r[2] == b"+" and len(r[1]) in (len(r[3]), len(r[3]) + 1) for r in recs)
+
+
+@pytest.mark.parametrize("T", [3, 64, 500])
+def test_default_model_many_lanes(ja, O, T):
+    g = ja.synthetic_genome([600_000], seed=42)
+    check_ref(ja, O, g, 700, T, seed=T)
+
+
+def test_custom_read_lengths_and_duplicates(ja, O):
+    g = ja.synthetic_genome([300_000, 10_000], seed=43)
+    check_ref(ja, O, g, 600, 16, {"custom_read_lengths": [[100, 1], [2500, 2], [57, 1], [9000, 0.5]]})
+    check_ref(ja, O, g, 600, 16, {"custom_read_lengths": [300, 1200, 5000], "prob_dup": 0.4, "read_pool_size": 7})
+    check_ref(ja, O, g, 300, 5, {"prob_dup": 0.9, "read_pool_size": 3})
+
+
+def test_other_error_models(ja, O):
+    g = ja.synthetic_genome([500_000], seed=44)
+    check_ref(ja, O, g, 300, 8, {"ins_prob": 0.02, "del_prob": 0.15, "sub_prob": 0.05, "prob_thresh": 0.3})
+    check_ref(ja, O, g, 300, 8, {"max_passes": 5, "sqrt_params": (0.8, 0.3), "norm_params": (0.1, 0.35)})
+    check_ref(ja, O, g, 300, 8, {"lognorm_read_length": (0.35, -500.0, 3000.0), "min_read_length": 400})
+    check_ref(ja, O, g, 300, 8, {"norm_params": (-3.0, 0.2)})      # far-tail branch of trunc_norm
+
+
+def test_non_tcag_bases_are_copied_like_the_reference(ja, O):
+    rng = np.random.default_rng(45)
+    seq = np.frombuffer(b"TCAGTCAGTCAGNnRY-", dtype=np.uint8)[rng.integers(0, 17, size=250_000)]
+    g = ja.RefGenome([seq])
+    check_ref(ja, O, g, 200, 6, {"custom_read_lengths": [800, 3000]})
+
+
+def test_haplotypes(ja, O):
+    ref = ja.synthetic_genome([250_000, 60_000], seed=46)
+    hs = random_haplotypes(ref, 3, seed=47, sub_rate=0.01, ins_rate=0.004, del_rate=0.004)
+    T, n = 12, 400
+    words = ja.seed_words(3, hs.seed_budget(T))
+    pb = {"custom_read_lengths": [500, 2000, 7000], "prob_dup": 0.1}
+    o, used_o, _ = O.pacbio_hap(hs, pb, hap_probs=[1.0, 2.0, 0.5], n_reads=n, n_threads=T, words=words)
+    h, reads, used_h = hip(ja, hs, n, T, words, dict(pb, haplotype_probs=[1.0, 2.0, 0.5]))
+    assert used_o == used_h
+    if h != o:
+        raise AssertionError("FASTQ differs at byte %d:\nHIP    %r\noracle %r" % first_diff(h, o))
+    o2, _, _ = O.pacbio_hap(hs, {}, hap_probs=[1.0, 1.0, 1.0], n_reads=120, n_threads=4, words=words)
+    h2, _, _ = hip(ja, hs, 120, 4, words, {})
+    assert h2 == o2
+
+
+def test_lane_shards_and_files(ja, O, tmp_path):
+    g = ja.synthetic_genome([400_000], seed=48)
+    T, n = 40, 500
+    words = ja.seed_words(6, 16 * T)
+    whole, _, _ = hip(ja, g, n, T, words, {})
+    parts = [hip(ja, g, n, T, words, {}, lane_begin=lo, lane_end=hi)[0] for lo, hi in [(0, 13), (13, 40)]]
+    assert b"".join(parts) == whole
+    small, _, _ = hip(ja, g, n, T, words, {}, max_batch_bytes=3_000_000)
+    assert small == whole
+    prefix = str(tmp_path / "pb")
+    ja.pacbio(g, prefix, n, n_threads=T, seed_words=words)
+    assert open(prefix + "_R1.fq", "rb").read() == whole

@@ -62,3 +62,15 @@ def test_pcg_and_gamma_streams(O, built):
         assert (g1 == g2).all(), (shape, scale)
     _abi.lib().jk_eval_set_gamma(16.0, 25.0)
     O.lib().orc_set_gamma(C.c_double(16.0), C.c_double(25.0))
+
+
+@pytest.mark.parametrize("name,op,per", __import__("test_host_primitives").PB_OPS)
+def test_pacbio_math_on_device(O, built, name, op, per):
+    from test_host_primitives import pacbio_math_inputs, orc2
+    x = pacbio_math_inputs(2_000_000, 4)[name].view(np.uint64)
+    n = x.size // per
+    out = np.zeros(n, dtype=np.uint64)
+    _abi.check(_abi.lib().jk_dev_eval(0, op, np.ascontiguousarray(x).ctypes.data, n, 0, out.ctypes.data))
+    b = orc2(O, op, x, per)
+    ok = out != np.uint64(2 ** 64 - 1)
+    assert ok.mean() > 0.99 and (out[ok] == b[ok]).all(), "%s differs on device" % name

@@ -121,3 +121,83 @@ def test_split_int_and_reads_per_group(O, built, ja):
                                              out2.ctypes.data_as(C.c_void_p), C.byref(used))
             assert rc == 0 and (out1 == out2).all() and int(out1.sum()) == n_reads
             assert words.size - src.n_words == used.value == (8 if n_reads > 0 else 0)
+
+
+# ---- PacBio arithmetic (csrc/jk_math2.h, jk_nmath.h) ---------------------------------------------
+
+def eval2(fn, what, xs, per=1):
+    xs = np.ascontiguousarray(xs, dtype=np.uint64)
+    n = xs.size // per
+    out = np.zeros(n, dtype=np.uint64)
+    _abi.check(fn(what, xs.ctypes.data, n, 0, out.ctypes.data))
+    return out
+
+
+def orc2(O, what, xs, per=1):
+    xs = np.ascontiguousarray(xs, dtype=np.uint64)
+    n = xs.size // per
+    out = np.zeros(n, dtype=np.uint64)
+    O.lib().orc_eval_many(what, xs.ctypes.data, n, 0, out.ctypes.data)
+    return out
+
+
+def pacbio_math_inputs(n, seed):
+    rng = np.random.default_rng(seed)
+    d = {}
+    d["exp"] = np.concatenate([rng.normal(0, 5, n), rng.uniform(-20, 20, n), rng.normal(9.8, 0.3, n),
+                               np.array([0.0, 1e-20, -1e-20, 1.0, -1.0])])
+    bx = np.concatenate([rng.uniform(0.001, 1, n), np.full(n, 2.0), rng.uniform(1, 1e6, n)])
+    ey = np.concatenate([rng.uniform(0.6, 12, n), rng.uniform(-40, 10, n), np.full(n, 1.4691051212330266)])
+    xy = np.empty(2 * bx.size)
+    xy[0::2], xy[1::2] = bx, ey
+    d["pow"] = xy
+    d["log10"] = np.concatenate([rng.uniform(1e-30, 1, n), rng.uniform(0, 1, n) ** 8, np.exp(rng.normal(0, 100, n))])
+    d["qnorm"] = np.concatenate([rng.uniform(0, 1, n), rng.uniform(0, 1e-8, n), 1 - rng.uniform(0, 1e-8, n),
+                                 rng.uniform(0, 1, n) ** 20])
+    ps = np.concatenate([rng.uniform(0, 1, 200), rng.uniform(0, 1e-6, 100), 1 - rng.uniform(0, 1e-9, 100),
+                         np.array([0.5, 0.25, 1e-300, 0.9999999999999999])])
+    reps = max(n // ps.size, 1)
+    xs = rng.integers(0, 2 ** 64, size=ps.size * reps, dtype=np.uint64)
+    quad = np.zeros(4 * xs.size, dtype=np.uint64)
+    quad[0::4] = xs
+    quad[1::4] = np.repeat(ps, reps).view(np.uint64)
+    for i, p in enumerate(ps):
+        m, e = C.c_uint64(), C.c_int32()
+        _abi.lib().jk_x87_one_minus(C.c_double(p), C.byref(m), C.byref(e))
+        quad[4 * i * reps + 2:4 * (i + 1) * reps:4] = m.value
+        quad[4 * i * reps + 3:4 * (i + 1) * reps:4] = np.int64(e.value).astype(np.uint64)
+    d["runif_ab"] = quad
+    return d
+
+
+PB_OPS = [("exp", _abi.OP_EXP, 1), ("pow", _abi.OP_POW, 2), ("log10", _abi.OP_LOG10, 1), ("qnorm", _abi.OP_QNORM, 1),
+          ("runif_ab", _abi.OP_RUNIF_AB, 4)]
+
+
+@pytest.mark.parametrize("name,op,per", PB_OPS)
+def test_pacbio_math_matches_host_libm_and_x87(O, built, name, op, per):
+    """jk_exp / jk_pow / jk_log10 restate glibc 2.35 (FMA variants); runif_ab is x87 emulation; qnorm is AS 241."""
+    x = pacbio_math_inputs(500_000, 3)[name]
+    a = eval2(_abi.lib().jk_host_eval, op, x.view(np.uint64), per)
+    b = orc2(O, op, x.view(np.uint64), per)
+    ok = a != np.uint64(2 ** 64 - 1)          # ~0 marks "outside the transcribed main path"
+    assert ok.mean() > 0.99
+    assert (a[ok] == b[ok]).all(), "%s differs on %d inputs" % (name, int((a[ok] != b[ok]).sum()))
+
+
+def test_nmath_restatements_against_scipy(O, built):
+    """pnorm (Cody) and qchisq are restatements of published algorithms (R itself is unavailable: parity with R
+    unpinned); they must at least agree with an independent implementation to rounding level."""
+    from scipy.stats import norm, chi2
+    from scipy.special import ndtri
+    O.lib().orc_pnorm.restype = C.c_double
+    O.lib().orc_pnorm.argtypes = [C.c_double]
+    O.lib().orc_qchisq.restype = C.c_double
+    O.lib().orc_qchisq.argtypes = [C.c_double, C.c_double]
+    for x in np.linspace(-30, 8, 400):
+        assert abs(O.lib().orc_pnorm(x) - norm.cdf(x)) <= 5e-13 * norm.cdf(x) + 1e-300
+    for df in list(np.linspace(2.0, 13, 60)) + [0.5, 50, 300]:
+        assert abs(O.lib().orc_qchisq(0.9925, df) - chi2.ppf(0.9925, df)) <= 1e-12 * chi2.ppf(0.9925, df)
+    p = np.random.default_rng(1).uniform(0, 1, 20000)
+    q = eval2(_abi.lib().jk_host_eval, _abi.OP_QNORM, p.view(np.uint64)).view(np.float64)
+    assert np.max(np.abs(q - ndtri(p)) / np.maximum(np.abs(ndtri(p)), 1e-12)) < 1e-13
