@@ -85,8 +85,10 @@ def main():
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("JK_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import jackalope_amd as ja
@@ -103,7 +105,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -130,7 +132,7 @@ def main():
     offsets, (total_reads, total_bytes) = exchange_counts(reads_made, sizes, device="cuda")
     total_pairs = total_reads // 2
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
@@ -172,7 +174,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(genome, p1, p2, read_length, sample, cores)
         print(json.dumps(out))
     sess.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -23,7 +23,7 @@ def exchange_counts(reads, bytes_per_end, device=None):
     import torch
     import torch.distributed as dist
     vals = [int(reads)] + [int(b) for b in bytes_per_end]
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [0] * len(bytes_per_end), (vals[0], vals[1:])
     t = torch.tensor(vals, dtype=torch.int64, device=device if device is not None else "cpu")
     gathered = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
