@@ -662,7 +662,8 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     // with a larger scale if a lane ran out (s.pool_scale)
     const uint64_t rec = max_hdr + n_digits(max_chrom) + 3 + 2 * M.len_hi + 8;
     std::vector<uint64_t> lane_cap(s.n_shard);
-    for (uint64_t l = 0; l < s.n_shard; l++) lane_cap[l] = (uint64_t)((double)(lane_reads[l] * rec) * s.pool_scale) + 2 * M.len_cap + 64;
+    for (uint64_t l = 0; l < s.n_shard; l++)       // per-lane regions are contiguous and hold whole 128-byte lines
+        lane_cap[l] = align_up((uint64_t)((double)(lane_reads[l] * rec) * s.pool_scale) + 2 * M.len_cap + 64, 128) + 128;
     const uint32_t max_lanes = plan_pools_common(s, max_batch_bytes ? max_batch_bytes : (32ULL << 30), 1ULL << 17,
                                                  lane_cap, lane_reads, lane_seeds, quotas);
     s.ev_words = (uint32_t)((2 * M.len_cap + 64 + 31) / 32);
@@ -818,7 +819,7 @@ static void launch_generate(jk_session& s) {
             hipLaunchKernelGGL(scan_block_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lb, lo, bs, B.n_lanes);
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.cp_stream, bs, nbp, base);
             hipLaunchKernelGGL(scan_add_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lo, bs, B.n_lanes);
-            hipLaunchKernelGGL(compact_pools_kernel, dim3((B.n_lanes + 63) / 64), dim3(256), 0, s.cp_stream,
+            hipLaunchKernelGGL(compact_linear_kernel, dim3(B.n_lanes), dim3(256), 0, s.cp_stream,
                                s.d_pool[pp][0].as<uint8_t>(), Q.pool_off, lb, lo, s.d_out[0].as<uint8_t>(), base, B.n_lanes);
             JK_HIP(hipGetLastError());
             JK_HIP(hipEventRecord(s.cp_done[b], s.cp_stream));

@@ -635,6 +635,27 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
     }
 }
 
+// Pool compaction for per-lane contiguous regions (PacBio): one 256-thread workgroup copies one lane's
+// text (16-byte aligned source, arbitrary destination alignment) in 16-byte pieces.
+__global__ void __launch_bounds__(256)
+compact_linear_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
+                      const uint64_t* __restrict__ lane_bytes, const uint64_t* __restrict__ out_off,
+                      uint8_t* __restrict__ out, const uint64_t* __restrict__ out_base, uint32_t n_lanes) {
+    const uint32_t lane = blockIdx.x;
+    if (lane >= n_lanes) return;
+    const uint32_t tile = lane >> 6;
+    const uint64_t cap = (pool_off[tile + 1] - pool_off[tile]) >> 6;
+    const uint8_t* src = pool + pool_off[tile] + (uint64_t)(lane & 63u) * cap;
+    uint8_t* dst = out + out_base[0] + out_off[lane];
+    const uint64_t n = lane_bytes[lane], n16 = n >> 4;
+    for (uint64_t c = threadIdx.x; c < n16; c += 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src + c * 16);
+        __builtin_memcpy(dst + c * 16, &v, 16);
+    }
+    const uint64_t tail = n16 << 4;
+    if (tail + threadIdx.x < n) dst[tail + threadIdx.x] = src[tail + threadIdx.x];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Exclusive scan of per-lane byte counts (u64), three small kernels.
 // ---------------------------------------------------------------------------------------------

@@ -5,8 +5,11 @@
 // PacBioQualityError::{sample,update_probs,trunc_norm,fill_quals} (src/hts_pacbio.h:266-398,
 // src/hts_pacbio.cpp:96-131), PacBioHaplotypes::{one_read,re_read} (src/hts_pacbio.cpp:488-551).
 //
-// Same execution model as the Illumina kernel: one GPU thread = one lane = one reference thread, the
-// lane appends FASTQ text to its column of a 64-lane pool tile.  Per read the reference makes two
+// Same execution model as the Illumina kernel: one GPU thread = one lane = one reference thread.  Unlike
+// Illumina reads, PacBio reads differ in length by thousands of bases, so the lanes of a wave drift far
+// apart in their output position and the word-interleaved pool tiles would turn every 4-byte store into
+// its own 32-byte memory transaction (measured: WRITE_SIZE 8.4x the FASTQ bytes).  Here each lane owns a
+// contiguous pool region and stages its text in LDS, 128 bytes per lane, leaving as whole 128-byte lines.  Per read the reference makes two
 // passes over the read's positions: (1) one draw per position classifies it as plain / insertion /
 // deletion / substitution, (2) the bases are emitted with one more draw per insertion or
 // substitution.  Pass 1 stores 2 bits per position in a per-lane HBM scratch laid out
@@ -65,17 +68,73 @@ struct PacbioKernelParams {
     uint64_t pool_size;
 };
 
-__device__ __forceinline__ void os_fill(OutStream& s, uint32_t byte, uint64_t count) {
-    s.pos += (uint32_t)count;
-    while (count && s.cnt) { os_put_raw(s, byte); count--; if (s.cnt >= 4u) os_store_word(s); }
-    const uint32_t w = byte * 0x01010101u;
-    while (count >= 4) { *reinterpret_cast<uint32_t*>(s.wp) = w; s.wp += TILE_ROW; count -= 4; }
-    while (count) { os_put_raw(s, byte); count--; }
+// Exact integer cut points of the comparisons pass 1 makes against a per-read probability c:
+// u(x) = (double)runif_01 is monotone in the raw draw x, so {x : u(x) < c} and {x : u(x) <= c} are prefixes
+// [0, t); found by bisection once per read instead of converting every draw to double.
+// Returns t, with t = 0 meaning "no x" and *all = true meaning "every x".
+template <bool LE>
+__device__ __forceinline__ uint64_t cut_point(double c, bool* all) {
+    *all = false;
+    auto pred = [&](uint64_t x) { const double u = jk_runif_double(x); return LE ? (u <= c) : (u < c); };
+    if (!pred(0)) return 0;
+    if (pred(~0ULL)) { *all = true; return 0; }
+    uint64_t lo = 0, hi = ~0ULL;             // pred(lo) true, pred(hi) false
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (pred(mid)) lo = mid; else hi = mid;
+    }
+    return hi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Line-staged appender: bytes -> 32-bit word in a register -> the lane's 128-byte line in LDS
+// (layout [word/4][thread][word%4], so a lane's 16-byte pieces are contiguous for ds_read_b128) ->
+// eight 16-byte global stores when the line is full.  Only the owning thread touches its LDS line.
+// ---------------------------------------------------------------------------------------------
+constexpr int PB_BLOCK = 256;
+struct LineStream {
+    uint8_t* gp;       // global address of the line being filled (128-byte aligned)
+    uint32_t* lds;     // this thread's slot 0: lds[(w >> 2) * PB_BLOCK * 4 + (w & 3)] is word w of the line
+    uint32_t w;        // bytes gathered for the current word
+    uint32_t pos;      // byte offset in the lane's stream of the next byte
+};
+__device__ __forceinline__ void ls_flush_line(LineStream& s) {
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(s.lds + q * PB_BLOCK * 4);
+        *reinterpret_cast<uint4*>(s.gp + q * 16) = v;
+    }
+    s.gp += 128;
+}
+__device__ __forceinline__ void ls_word_done(LineStream& s) {       // pos is a multiple of 4 here
+    const uint32_t wi = ((s.pos >> 2) - 1u) & 31u;
+    s.lds[(wi >> 2) * PB_BLOCK * 4 + (wi & 3u)] = s.w;
+    s.w = 0;
+    if (wi == 31u) ls_flush_line(s);
+}
+__device__ __forceinline__ void ls_put(LineStream& s, uint32_t byte) {
+    s.w |= byte << (8u * (s.pos & 3u));
+    s.pos++;
+    if ((s.pos & 3u) == 0) ls_word_done(s);
+}
+__device__ __forceinline__ void ls_fill(LineStream& s, uint32_t byte, uint64_t count) {
+    while (count && (s.pos & 3u)) { ls_put(s, byte); count--; }
+    const uint32_t word = byte * 0x01010101u;
+    while (count >= 4) { s.w = word; s.pos += 4; ls_word_done(s); count -= 4; }
+    while (count) { ls_put(s, byte); count--; }
+}
+// end of the lane's stream: write the partial line (whole words from LDS, then the pending bytes)
+__device__ __forceinline__ void ls_finish(LineStream& s) {
+    const uint32_t nw = (s.pos >> 2) & 31u;
+    for (uint32_t wi = 0; wi < nw; wi++)
+        *reinterpret_cast<uint32_t*>(s.gp + wi * 4) = s.lds[(wi >> 2) * PB_BLOCK * 4 + (wi & 3u)];
+    for (uint32_t j = 0; j < (s.pos & 3u); j++) s.gp[nw * 4 + j] = (uint8_t)(s.w >> (8u * j));
 }
 
 template <bool HAP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(PB_BLOCK, 4)       // 4 waves per SIMD -> at most 128 VGPRs
 pacbio_kernel(PacbioKernelParams P) {
+    __shared__ __align__(16) uint32_t stage[32 * PB_BLOCK];     // 128 bytes per thread
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= P.n_lanes) return;
 
@@ -93,10 +152,11 @@ pacbio_kernel(PacbioKernelParams P) {
 
     const uint32_t tile = lane >> 6;
     const uint64_t tile_off = P.pool_off[tile];
-    const uint64_t lane_cap = (P.pool_off[tile + 1] - tile_off) >> 6;
-    uint8_t* const base = P.pool + tile_off + (lane & 63u) * 4u;
-    OutStream o;
-    os_begin(o, base, 0);
+    const uint64_t lane_cap = (P.pool_off[tile + 1] - tile_off) >> 6;      // a multiple of 128 (host)
+    LineStream o;
+    o.gp = P.pool + tile_off + (uint64_t)(lane & 63u) * lane_cap;           // this lane's contiguous region
+    o.lds = stage + threadIdx.x * 4;
+    o.w = 0; o.pos = 0;
 
     uint32_t err = 0;
     const size_t ev_stride = (size_t)P.n_lanes;
@@ -211,22 +271,29 @@ pacbio_kernel(PacbioKernelParams P) {
         // ---- pass 1: one draw per position (PacBioQualityError::sample, src/hts_pacbio.h:292-317)
         uint64_t cur = 0, pos = 0, extra = chrom_len - L, n_ins = 0, n_del = 0;
         {
-            const double* cum = cumL;
+            // u > cum[2]  <=>  x >= t_none ; u < cum[0]  <=>  x < t_ins ; u < cum[1]  <=>  x < t_del
+            uint64_t tL[3], tR[3]; bool aL[3], aR[3];
+            tL[0] = cut_point<true>(cumL[2], &aL[0]); tL[1] = cut_point<false>(cumL[0], &aL[1]); tL[2] = cut_point<false>(cumL[1], &aL[2]);
+            tR[0] = cut_point<true>(cumR[2], &aR[0]); tR[1] = cut_point<false>(cumR[0], &aR[1]); tR[2] = cut_point<false>(cumR[1], &aR[2]);
+            uint64_t t_none = tL[0], t_ins = tL[1], t_del = tL[2];
+            bool never_none = aL[0], all_ins = aL[1], all_del = aL[2];
+            auto go_right = [&]() { t_none = tR[0]; t_ins = tR[1]; t_del = tR[2]; never_none = aR[0]; all_ins = aR[1]; all_del = aR[2]; };
             uint64_t word = 0;
             while (cur < L) {
-                if (cur == split_pos) cum = cumR;
-                const double u = jk_runif_double(rng());
-                uint64_t type = 0;
-                if (u > cum[2]) {
-                    cur++;
-                } else if (u < cum[0]) {
-                    if (cur < L - 1) { type = 1; n_ins++; cur++; extra++; if (cur == split_pos) cum = cumR; }
-                    cur++;
-                } else if (u < cum[1]) {
-                    if (extra > 0) { type = 2; n_del++; extra--; }
-                } else {
-                    type = 3; cur++;
-                }
+                if (cur == split_pos) go_right();
+                const uint64_t x = rng();
+                // same decision tree as the reference (src/hts_pacbio.h:296-314), written without divergent branches
+                const bool none = !never_none && x >= t_none;
+                const bool ins = !none && (all_ins || x < t_ins);
+                const bool del = !none && !ins && (all_del || x < t_del);
+                const bool sub = !none && !ins && !del;
+                const bool ins_rec = ins && (cur < L - 1);           // an insertion at the last base is not recorded
+                const bool del_rec = del && (extra > 0);              // nor a deletion without spare chromosome
+                const uint64_t type = ins_rec ? 1u : (del_rec ? 2u : (sub ? 3u : 0u));
+                n_ins += ins_rec ? 1u : 0u; n_del += del_rec ? 1u : 0u;
+                extra = extra + (ins_rec ? 1u : 0u) - (del_rec ? 1u : 0u);
+                if (ins_rec) { cur++; if (cur == split_pos) go_right(); }
+                cur += del ? 0u : 1u;
                 if (pos >= max_pos) { err |= JK_KERR_PB_TOO_LONG; break; }
                 word |= type << (2u * (pos & 31u));
                 pos++;
@@ -262,7 +329,7 @@ pacbio_kernel(PacbioKernelParams P) {
             {
                 uint32_t hdr_len = P.g.hdr_off[ci + 1] - P.g.hdr_off[ci];
                 if ((uint64_t)o.pos + hdr_len + 24 + 2 * L + 8 > lane_cap) { err |= JK_KERR_POOL_OVERFLOW; break; }
-                for (uint32_t h = P.g.hdr_off[ci]; h < P.g.hdr_off[ci + 1]; h++) os_put(o, P.g.hdr_blob[h]);
+                for (uint32_t h = P.g.hdr_off[ci]; h < P.g.hdr_off[ci + 1]; h++) ls_put(o, P.g.hdr_blob[h]);
                 uint64_t v = read_start, packed_lo = 0, packed_hi = 0; uint32_t nd = 0;
                 do {
                     const uint64_t q = v / 10, d = v - q * 10;
@@ -271,12 +338,12 @@ pacbio_kernel(PacbioKernelParams P) {
                     v = q; nd++;
                 } while (v);
                 for (uint32_t d = 0; d < nd; d++) {
-                    os_put(o, '0' + (uint32_t)(packed_lo & 15u));
+                    ls_put(o, '0' + (uint32_t)(packed_lo & 15u));
                     packed_lo = (packed_lo >> 4) | (packed_hi << 60); packed_hi >>= 4;
                 }
-                os_put(o, '-');
-                os_put(o, reverse ? 'R' : 'F');
-                os_put(o, '\n');
+                ls_put(o, '-');
+                ls_put(o, reverse ? 'R' : 'F');
+                ls_put(o, '\n');
             }
             // source walker: read[p] = forward chrom[start + p], reverse cmp(chrom[start + space - 1 - p])
             const uint8_t* const gseq = P.g.seq;
@@ -314,6 +381,10 @@ pacbio_kernel(PacbioKernelParams P) {
             if (space > 0) seg_enter(0);
 
             // ---- pass 2: emit bases
+            // The four cases (plain / insertion / deletion / substitution) are folded into one straight-line
+            // body: with 64 lanes almost every position has some lane in each case, so separate branches would
+            // all be executed at every position.  The extra draw is computed for every lane on a copy of the
+            // engine and only committed by lanes whose position is an insertion or a substitution.
             uint64_t cur2 = 0, p2 = 0, evw = 0;
             while (cur2 < L) {
                 if ((p2 & 31u) == 0) evw = (p2 < pos) ? evl[(p2 >> 5) * ev_stride] : 0;
@@ -324,32 +395,30 @@ pacbio_kernel(PacbioKernelParams P) {
                 if (HAP && p2 >= seg_end) seg_enter(p2);
                 const uint32_t c = src_next();
                 // character of read[p2] as the reference sees it (cmp_map for the reverse strand)
-                uint32_t ch, nt;
-                if (c < 4u) { nt = reverse ? (c ^ 2u) : c; ch = base_char(nt); }
-                else { nt = 4u; ch = reverse ? (c == 'N' ? 'N' : 0u) : c; }
-                if (type == 1u) {
-                    const uint32_t r4 = (uint32_t)jk_runif_index(rng(), 4);
-                    os_put(o, ch);
-                    os_put(o, r4 < 4u ? base_char(r4) : 0u);
-                    cur2 += 2;
-                } else if (type == 2u) {
-                    // deletion: nothing emitted
-                } else if (type == 3u) {
-                    const uint32_t m = runif_index32(rng(), 3);
-                    const uint32_t sub = (nt < 4u) ? ((m < 3u) ? base_char(m + (m >= nt ? 1u : 0u)) : 0u) : ((m < 3u) ? 'N' : 0u);
-                    os_put(o, sub);
-                    cur2++;
-                } else {
-                    os_put(o, ch);
-                    cur2++;
-                }
+                const bool is_nt = c < 4u;
+                const uint32_t nt = is_nt ? (reverse ? (c ^ 2u) : c) : 4u;
+                const uint32_t ch = is_nt ? base_char(nt) : (reverse ? (c == 'N' ? (uint32_t)'N' : 0u) : c);
+                jk_pcg64 e2 = rng.e;
+                const uint64_t x = jk_pcg_next(e2);
+                const bool is_ins = type == 1u, is_del = type == 2u, is_sub = type == 3u;
+                if (is_ins | is_sub) rng.e = e2;                       // only these cases consume a draw
+                const uint32_t r4 = (uint32_t)jk_runif_index(x, 4);    // insertion: jlp::bases[(uint64)(runif_01 * 4)]
+                const uint32_t m = runif_index32(x, 3);                // substitution: mm_nucleos[nt][(uint64)(runif_01 * 3)]
+                const uint32_t ins_ch = r4 < 4u ? base_char(r4) : 0u;
+                const uint32_t sub_ch = (m < 3u) ? (is_nt ? base_char(m + (m >= nt ? 1u : 0u)) : (uint32_t)'N') : 0u;
+                const uint32_t b0 = is_sub ? sub_ch : ch;
+                const uint32_t nb = is_del ? 0u : (is_ins ? 2u : 1u);
+                const uint32_t two = b0 | (ins_ch << 8);
+                if (nb >= 1u) ls_put(o, two & 0xffu);
+                if (nb == 2u) ls_put(o, two >> 8);
+                cur2 += nb;
                 p2++;
             }
             if (err) break;
-            os_put(o, '\n'); os_put(o, '+'); os_put(o, '\n');
-            os_fill(o, qual_left, split_pos < L ? split_pos : L);
-            os_fill(o, qual_right, split_pos < L ? L - split_pos : 0);
-            os_put(o, '\n');
+            ls_put(o, '\n'); ls_put(o, '+'); ls_put(o, '\n');
+            ls_fill(o, qual_left, split_pos < L ? split_pos : L);
+            ls_fill(o, qual_right, split_pos < L ? L - split_pos : 0);
+            ls_put(o, '\n');
         }
         if (HAP) ccnt = ccnt > 0 ? ccnt - 1 : 0;     // n_reads_vc[hap][chr]-- (one_read) / if > 0 (re_read)
 
@@ -360,7 +429,7 @@ pacbio_kernel(PacbioKernelParams P) {
         if (dup && made < quota && in_pool < P.pool_size) is_dup = true;
         else { is_dup = false; if (in_pool >= P.pool_size || made >= quota) in_pool = 0; }
     }
-    os_flush(o);
+    ls_finish(o);
     P.lane_bytes[lane] = o.pos;
     if (o.pos > lane_cap) err |= JK_KERR_POOL_OVERFLOW;
     P.lane_made[lane] = made;
