@@ -104,8 +104,8 @@ typedef struct jk_illumina_args {
     int32_t matepair;
     const char* out_prefix;           /* files <prefix>_R1.fq[, <prefix>_R2.fq] (src/hts.h:342-346) */
     int32_t sep_files;                /* hap only: one pair of files per haplotype (src/hts.h:512-552) */
-    int32_t compress;                 /* only 0 is implemented on this path (JK_ERR_UNSUPPORTED otherwise) */
-    const char* comp_method;
+    int32_t compress;                 /* 0 = plain, 1..9 = level; files get ".gz" appended (src/io.h) */
+    const char* comp_method;          /* "bgzip" (BGZF, default) or "gzip" */
     uint64_t n_reads;
     double prob_dup;
     uint64_t n_threads;               /* number of lanes, see header comment */
@@ -132,7 +132,7 @@ typedef struct jk_illumina_args {
 typedef struct jk_pacbio_args {
     const char* out_prefix;           /* file <prefix>_R1.fq */
     int32_t sep_files;                /* hap only */
-    int32_t compress;                 /* only 0 is implemented */
+    int32_t compress;                 /* 0 = plain, 1..9 = level */
     const char* comp_method;
     uint64_t n_reads;
     uint64_t n_threads;               /* number of lanes */
@@ -184,7 +184,9 @@ int jk_session_sizes(const jk_session* s, uint64_t bytes[2], uint64_t* reads, ui
 int jk_session_device_ptr(const jk_session* s, uint32_t end, const void** dptr);
 /* Copy the FASTQ image of read end e to host memory (cap >= bytes[e]). */
 int jk_session_fetch(const jk_session* s, uint32_t end, void* dst, uint64_t cap);
-/* Write <out_prefix>_R<e+1>.fq for every end (uncompressed, FileUncomp src/io.h:242-295). */
+/* Write <out_prefix>_R<e+1>.fq[.gz] for every end: FileUncomp / FileGZ / FileBGZF of src/io.h:58-295,
+ * chosen by args.compress and args.comp_method.  Compression runs on the host after generation, as the
+ * reference does for n_threads > 1 (src/hts.h:478-490). */
 int jk_session_write(const jk_session* s);
 /* Timing of the last generate(): HIP-event milliseconds on the session's stream.
  * ms[0] generator kernel(s), ms[1] scan + compaction kernels, ms[2] whole generate() (device). */

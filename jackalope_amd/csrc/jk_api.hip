@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <thread>
+#include <zlib.h>
 #include <memory>
 #include <string>
 #include <vector>
@@ -81,6 +83,8 @@ struct jk_session {
     bool lds_tables = false;
     size_t lds_bytes = 0;
     bool hap = false;
+    int compress = 0;          // 0 = plain FASTQ, 1..9 = compression level
+    bool bgzip = true;         // comp_method: "bgzip" (BGZF blocks) or "gzip"
     bool pacbio = false;
     PacbioKernelParams kpb{};
     DevBuf d_len_thresh, d_len_alias, d_lens, d_thr_tab, d_pass_tab, d_ev2;
@@ -147,13 +151,22 @@ static void upload_genome(jk_session& s, const jk_ref_genome& g, const char* blo
     s.n_chroms = (uint32_t)g.n_chroms;
 }
 
+// compress / comp_method of the reference's entry points (write_reads_cpp_, src/hts.h:453-496)
+static void set_compression(jk_session& s, int compress, const char* comp_method) {
+    if (compress < 0 || compress > 9) throw Error(JK_ERR_ARG, "\nInvalid bgzip compress level of " + std::to_string(compress) + ". It must be in range [0,9].");
+    s.compress = compress;
+    const std::string m = comp_method ? comp_method : "bgzip";
+    if (compress > 0 && m != "gzip" && m != "bgzip") throw Error(JK_ERR_ARG, "\nUnrecognized compression method.");
+    s.bgzip = (m != "gzip");
+}
+
 static inline uint8_t encode_base(char c) { return c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : 4; }
 
 // ---- pieces shared by the reference-genome and haplotype entry points --------------------------
 
 // Argument checks + error-model tables + every per-run constant of the kernel.
 static void setup_model(jk_session& s, const jk_illumina_args& a) {
-    if (a.compress > 0) throw Error(JK_ERR_UNSUPPORTED, "compressed FASTQ output is not implemented on the GPU path (write uncompressed, then gzip/bgzip)");
+    set_compression(s, a.compress, a.comp_method);
     if (a.frag_len_shape < 1.0) throw Error(JK_ERR_UNSUPPORTED, "frag_len_shape < 1 (fragment sd > mean) is not implemented on the GPU path");
     if (!(a.frag_len_scale > 0)) throw Error(JK_ERR_ARG, "frag_len_scale must be > 0");
     s.paired = a.paired != 0;
@@ -555,7 +568,7 @@ struct PacbioHostModel {
 };
 
 static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a, uint64_t max_chrom) {
-    if (a.compress > 0) throw Error(JK_ERR_UNSUPPORTED, "compressed FASTQ output is not implemented on the GPU path (write uncompressed, then gzip/bgzip)");
+    set_compression(s, a.compress, a.comp_method);
     if (!a.chi2_params_n || !a.chi2_params_s || !a.sqrt_params || !a.norm_params) throw Error(JK_ERR_ARG, "PacBio parameter vectors must not be NULL");
     s.pacbio = true; s.paired = false; s.n_ends = 1;
     s.out_prefix = a.out_prefix ? a.out_prefix : "";
@@ -905,21 +918,85 @@ static void launch_generate(jk_session& s) {
     s.generated = true;
 }
 
+// ---- output sinks (src/io.h:58-295): plain file, gzip (zlib gzFile) or BGZF ---------------------------
+// BGZF = concatenated gzip members of <= 0xff00 input bytes with a 'BC' extra field and a fixed empty
+// end-of-file member (the format htslib's bgzf_write produces; readable by gzip, zcat, bgzip, samtools).
+static const size_t BGZF_IN = 0xff00;
+
+static void bgzf_compress_block(const uint8_t* src, size_t n, int level, std::vector<uint8_t>& out) {
+    const size_t start = out.size();
+    out.resize(start + 18 + compressBound(n) + 8);
+    uint8_t* h = out.data() + start;
+    static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+    std::memcpy(h, head, 16);
+    z_stream zs;
+    std::memset(&zs, 0, sizeof(zs));
+    if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw Error(JK_ERR_IO, "deflateInit2 failed");
+    zs.next_in = const_cast<uint8_t*>(src); zs.avail_in = (uInt)n;
+    zs.next_out = h + 18; zs.avail_out = (uInt)(out.size() - start - 18 - 8);
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); throw Error(JK_ERR_IO, "deflate failed"); }
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    const size_t total = 18 + clen + 8;
+    if (total > 65536) throw Error(JK_ERR_IO, "BGZF block did not compress below 64 KiB");
+    h[16] = (uint8_t)((total - 1) & 0xff); h[17] = (uint8_t)((total - 1) >> 8);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n);
+    uint8_t* t = h + 18 + clen;
+    for (int i = 0; i < 4; i++) { t[i] = (uint8_t)(crc >> (8 * i)); t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i)); }
+    out.resize(start + total);
+}
+
 static void write_files(const jk_session& s) {
     if (!s.generated) throw Error(JK_ERR_ARG, "jk_session_write before jk_session_generate");
-    const size_t CH = 64u << 20;
-    std::vector<char> buf(CH);
+    const size_t CH = BGZF_IN * 1024;                     // 66.8 MB, a whole number of BGZF blocks
+    std::vector<uint8_t> buf(CH);
+    const unsigned n_thr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     for (uint32_t e = 0; e < s.n_ends; e++) {
-        const std::string fn = s.out_prefix + "_R" + std::to_string(e + 1) + ".fq";
-        FILE* f = std::fopen(fn.c_str(), "wb");
-        if (!f) throw Error(JK_ERR_IO, "Unable to open file " + fn + ".\n");
+        std::string fn = s.out_prefix + "_R" + std::to_string(e + 1) + ".fq";
+        if (s.compress > 0) fn += ".gz";
+        FILE* f = nullptr; gzFile gz = nullptr;
+        if (s.compress > 0 && !s.bgzip) {
+            const std::string mode = "wb" + std::to_string(s.compress);
+            gz = gzopen(fn.c_str(), mode.c_str());
+            if (!gz) throw Error(JK_ERR_IO, "gzopen of " + fn + " failed.\n");
+        } else {
+            f = std::fopen(fn.c_str(), "wb");
+            if (!f) throw Error(JK_ERR_IO, "Unable to open file " + fn + ".\n");
+        }
+        auto fail = [&](int code, const std::string& msg) { if (f) std::fclose(f); if (gz) gzclose(gz); throw Error(code, msg); };
         for (uint64_t off = 0; off < s.bytes[e]; off += CH) {
             const size_t n = (size_t)std::min<uint64_t>(CH, s.bytes[e] - off);
             hipError_t he = hipMemcpy(buf.data(), s.d_out[e].as<uint8_t>() + off, n, hipMemcpyDeviceToHost);
-            if (he != hipSuccess) { std::fclose(f); throw Error(JK_ERR_DEVICE, hipGetErrorString(he)); }
-            if (std::fwrite(buf.data(), 1, n, f) != n) { std::fclose(f); throw Error(JK_ERR_IO, "short write to " + fn); }
+            if (he != hipSuccess) fail(JK_ERR_DEVICE, hipGetErrorString(he));
+            if (s.compress == 0) {
+                if (std::fwrite(buf.data(), 1, n, f) != n) fail(JK_ERR_IO, "short write to " + fn);
+            } else if (!s.bgzip) {
+                if (gzwrite(gz, buf.data(), (unsigned)n) != (int)n) fail(JK_ERR_IO, "gzwrite to " + fn + " failed");
+            } else {
+                const size_t n_blocks = (n + BGZF_IN - 1) / BGZF_IN;
+                std::vector<std::vector<uint8_t>> parts(n_thr);
+                std::vector<std::string> errs(n_thr);
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < n_thr; t++) pool.emplace_back([&, t] {
+                    try {
+                        const size_t b0 = n_blocks * t / n_thr, b1 = n_blocks * (t + 1) / n_thr;
+                        for (size_t b = b0; b < b1; b++)
+                            bgzf_compress_block(buf.data() + b * BGZF_IN, std::min(BGZF_IN, n - b * BGZF_IN), s.compress, parts[t]);
+                    } catch (const std::exception& ex) { errs[t] = ex.what(); }
+                });
+                for (std::thread& th : pool) th.join();
+                for (unsigned t = 0; t < n_thr; t++) {
+                    if (!errs[t].empty()) fail(JK_ERR_IO, errs[t]);
+                    if (!parts[t].empty() && std::fwrite(parts[t].data(), 1, parts[t].size(), f) != parts[t].size()) fail(JK_ERR_IO, "short write to " + fn);
+                }
+            }
         }
-        if (std::fclose(f) != 0) throw Error(JK_ERR_IO, "error closing " + fn);
+        if (s.compress > 0 && s.bgzip) {
+            static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (std::fwrite(eof_block, 1, 28, f) != 28) fail(JK_ERR_IO, "short write to " + fn);
+        }
+        if (f && std::fclose(f) != 0) throw Error(JK_ERR_IO, "error closing " + fn);
+        if (gz && gzclose(gz) != Z_OK) throw Error(JK_ERR_IO, "error closing " + fn);
     }
 }
 

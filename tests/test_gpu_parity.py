@@ -165,11 +165,31 @@ def test_lane_shards_concatenate_to_the_whole(ja, O):
         assert int(lb.sum()) == len(whole1)
 
 
+def test_compressed_sinks(ja, O, tmp_path):
+    """FileGZ / FileBGZF (src/io.h:58-236): <prefix>_R{1,2}.fq.gz whose decompressed content is the plain FASTQ."""
+    import gzip
+    g = ja.synthetic_genome([60_000], seed=17)
+    words = ja.seed_words(4, 16 * 32)
+    plain1, plain2, _, _ = run_hip(ja, g, (None, None), 150, words, 4000, 32, job())
+    for method, level in (("bgzip", True), ("gzip", 1), ("bgzip", 9)):
+        prefix = str(tmp_path / ("z_%s_%s" % (method, level)))
+        ja.illumina(g, prefix, 4000, 150, True, n_threads=32 if method == "bgzip" else 1, seed_words=words,
+                    compress=level, comp_method=method) if method == "bgzip" else None
+        if method == "gzip":
+            w1 = ja.seed_words(4, 16)
+            ja.illumina(g, prefix, 400, 150, True, n_threads=1, seed_words=w1, compress=level, comp_method="gzip")
+            p1, _, _, _ = run_hip(ja, g, (None, None), 150, w1, 400, 1, job())
+            assert gzip.decompress(open(prefix + "_R1.fq.gz", "rb").read()) == p1
+            continue
+        raw = open(prefix + "_R1.fq.gz", "rb").read()
+        assert gzip.decompress(raw) == plain1 and gzip.decompress(open(prefix + "_R2.fq.gz", "rb").read()) == plain2
+        assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[12:14] == b"BC" and raw[-28:-24] == b"\x1f\x8b\x08\x04"   # BGZF framing + EOF block
+        assert not os.path.exists(prefix + "_R1.fq")
+
+
 def test_unsupported_inputs_fail_loudly(ja):
     g = ja.synthetic_genome([10_000], seed=16)
     words = ja.seed_words(1, 64)
-    with pytest.raises(ja.JackalopeHipError, match="compress"):
-        ja.illumina(g, None, 100, 150, True, n_threads=2, seed_words=words, compress=True, _session=True)
     with pytest.raises(ja.JackalopeHipError, match="shape"):
         ja.illumina(g, None, 100, 150, True, n_threads=2, seed_words=words, frag_mean=100, frag_sd=200, _session=True)
     with pytest.raises(ja.JackalopeHipError, match="seed"):
