@@ -62,6 +62,65 @@ def pmc_traffic(pairs_per_launch):
         return None
 
 
+def pacbio_main(a):
+    """Secondary line: PacBio reads (uniform 5-15 kb custom lengths, mean 10 kb) at 20x of a synthetic genome,
+    BASELINE configs[4] scaled by --genome-mbp (default 1000 Mbp per GPU).  Same timing contract."""
+    import torch
+    import jackalope_amd as ja
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        raise SystemExit("the PacBio line is single-GPU in this round")
+    torch.cuda.set_device(local_rank)
+    mbp = a.genome_mbp if a.genome_mbp != 100.0 else 1000.0
+    genome = ja.synthetic_genome([int(mbp * 1e6)], seed=3)
+    n_reads = int(mbp * 1e6 * 20 / 10000)
+    lanes = a.lanes
+    lens = list(range(5000, 15001, 500))
+    words = ja.seed_words(12345, 16 * lanes)
+    sess = ja.pacbio(genome, None, n_reads, n_threads=lanes, seed_words=words, custom_read_lengths=lens, device=local_rank,
+                     _session=True)
+    for _ in range(a.warmup):
+        sess.generate()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gen_ms = 0.0
+    for _ in range(a.steps):
+        sess.generate()
+        gen_ms += sess.timing_ms()["generate_kernel"]
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sizes, reads = sess.sizes()
+    n_launch = max(sess.n_batches(), 1)
+    alg = (sizes[0] + sizes[0] // 2) / n_launch                  # FASTQ bytes (~2 per base) + 1 reference byte per base
+    kern_s = gen_ms / a.steps / 1e3 / n_launch
+    out = {"metric": "M PacBio reads/sec (mean 10 kb, 20x)", "value": round(reads * a.steps / elapsed / 1e6, 3),
+           "unit": "M reads/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "config": {"workload": "configs[4]-style: %g Mbp synthetic ref, PacBio defaults, custom read lengths uniform "
+                                  "5-15 kb, 20x" % mbp, "reads_per_gpu": n_reads, "lanes_per_gpu": lanes},
+           "gbases_per_sec": round(sizes[0] / 2 * a.steps / elapsed / 1e9, 2),
+           "roofline": {"bound": "hbm", "achieved": round(alg / kern_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "pacbio_kernel<ref>",
+                        "launches_per_step": n_launch, "kernel_ms": round(kern_s * 1e3, 3)}}
+    if not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        cores = min(os.cpu_count() or 1, 64)
+        O.lib().orc_set_threads(cores)
+        cl = cores * 4
+        sample = 3000 * cl
+        t1 = time.perf_counter()
+        O.pacbio_ref(genome, {"custom_read_lengths": lens}, n_reads=sample, n_threads=cl, words=ja.seed_words(1, 16 * cl), discard=True)
+        dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(sample / dt / 1e6, 6), "unit": "M reads/sec", "cores": cores, "kind": "port",
+                               "sample": "%d reads of the same workload on %d lanes, oracle with OpenMP, null sink (%.1f s)" % (sample, cl, dt)}
+    print(json.dumps(out))
+    sess.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +131,11 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=100.0)
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = choose for about 15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["illumina", "pacbio"], default="illumina",
+                    help="illumina = the headline metric (BASELINE configs[1]); pacbio = configs[4]-style secondary line")
     a = ap.parse_args()
+    if a.workload == "pacbio":
+        return pacbio_main(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -677,7 +677,7 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     std::vector<uint64_t> lane_cap(s.n_shard);
     for (uint64_t l = 0; l < s.n_shard; l++)       // per-lane regions are contiguous and hold whole 128-byte lines
         lane_cap[l] = align_up((uint64_t)((double)(lane_reads[l] * rec) * s.pool_scale) + 2 * M.len_cap + 64, 128) + 128;
-    const uint32_t max_lanes = plan_pools_common(s, max_batch_bytes ? max_batch_bytes : (32ULL << 30), 1ULL << 17,
+    const uint32_t max_lanes = plan_pools_common(s, max_batch_bytes ? max_batch_bytes : (48ULL << 30), 1ULL << 18,
                                                  lane_cap, lane_reads, lane_seeds, quotas);
     s.ev_words = (uint32_t)((2 * M.len_cap + 64 + 31) / 32);
     s.d_ev2.alloc((size_t)s.ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
