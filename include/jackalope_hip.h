@@ -206,6 +206,25 @@ int jk_reads_per_group(uint64_t n_reads, const double* probs, uint64_t n,       
 void jk_alias_build(const double* probs, uint64_t n, double* Prob, uint64_t* Alias);   /* src/alias_sampler.h:68-106 */
 int jk_hap_chrom_full(const jk_hap_set* haps, uint64_t hap, uint64_t chrom, char* out, uint64_t cap); /* src/hap_classes.cpp:80-116 (host) */
 
+/* Mutation tables, write side (first "next" row): the haplotype objects the
+ * sequencers read are built by these three edits.  A builder is the reference's XPtr<HapSet>; the
+ * functions replace make_hap_set (src/ref_hap_access.cpp:127-132) and add_substitution /
+ * add_insertion / add_deletion (src/ref_hap_access.cpp:816-865 -> HapChrom::add_*,
+ * src/hap_classes.cpp:295-509), with the same 0-based indices and argument meaning.  Host code: the
+ * tables live in host memory until a sequencer session uploads them.  The chromosome bytes of `ref`
+ * are borrowed and must outlive the builder (as the RefGenome must outlive a HapSet); everything
+ * else of `ref` is copied. */
+typedef struct jk_hap_builder jk_hap_builder;
+int jk_hap_builder_new(const jk_ref_genome* ref, uint64_t n_haps, jk_hap_builder** out);
+/* Start from existing tables (e.g. read back from another tool) instead of an unmutated set. */
+int jk_hap_builder_from(const jk_hap_set* haps, jk_hap_builder** out);
+int jk_add_substitution(jk_hap_builder* b, uint64_t hap_ind, uint64_t chrom_ind, char nucleo, uint64_t new_pos);
+int jk_add_insertion(jk_hap_builder* b, uint64_t hap_ind, uint64_t chrom_ind, const char* nucleos, uint64_t new_pos);
+int jk_add_deletion(jk_hap_builder* b, uint64_t hap_ind, uint64_t chrom_ind, uint64_t size, uint64_t new_pos);
+/* Flat view of the current tables for jk_*_hap / jk_hap_chrom_full; valid until the next edit or free. */
+int jk_hap_builder_view(jk_hap_builder* b, jk_hap_set* out);
+void jk_hap_builder_free(jk_hap_builder* b);
+
 /* Elementary arithmetic of the path evaluated by the SAME inline functions the kernels use, on the
  * host (`jk_host_*`) and on the device (`jk_dev_*`, arrays of n inputs already in host memory; they
  * are copied to the GPU, evaluated there by one thread per element and copied back).  These exist

@@ -108,6 +108,8 @@ EXPORTS = [
     "jk_session_seed_words_used", "jk_session_batches", "jk_session_lane_bytes", "jk_session_close",
     "jk_split_int", "jk_reads_per_group", "jk_alias_build", "jk_hap_chrom_full",
     "jk_host_eval", "jk_dev_eval", "jk_eval_set_gamma", "jk_x87_one_minus",
+    "jk_hap_builder_new", "jk_hap_builder_from", "jk_add_substitution", "jk_add_insertion", "jk_add_deletion",
+    "jk_hap_builder_view", "jk_hap_builder_free",
 ]
 
 _lib = None
@@ -158,6 +160,14 @@ def lib():
     L.jk_alias_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.jk_alias_build.restype = None
     L.jk_hap_chrom_full.argtypes = [C.POINTER(HapSetView), C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
+    L.jk_hap_builder_new.argtypes = [C.POINTER(RefGenomeView), C.c_uint64, C.POINTER(C.c_void_p)]
+    L.jk_hap_builder_from.argtypes = [C.POINTER(HapSetView), C.POINTER(C.c_void_p)]
+    L.jk_add_substitution.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_char, C.c_uint64]
+    L.jk_add_insertion.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.c_uint64]
+    L.jk_add_deletion.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+    L.jk_hap_builder_view.argtypes = [C.c_void_p, C.POINTER(HapSetView)]
+    L.jk_hap_builder_free.argtypes = [C.c_void_p]
+    L.jk_hap_builder_free.restype = None
     L.jk_host_eval.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     L.jk_dev_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     L.jk_eval_set_gamma.argtypes = [C.c_double, C.c_double]

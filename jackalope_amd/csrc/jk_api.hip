@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/jackalope_hip.h"
+#include "jk_haps.h"
 #include "jk_host.h"
 #include "jk_illumina_kernel.h"
 #include "jk_math2.h"
@@ -434,7 +435,8 @@ static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min
                                                      : (int64_t)(cell_size[k] - ref_len);
             smod += (int64_t)(hs.old_pos[m] - hs.new_pos[m]);
             const uint64_t have = hs.nuc_off[m + 1] - hs.nuc_off[m];
-            if (m > cell_off[k] && hs.new_pos[m] <= hs.new_pos[m - 1]) throw Error(JK_ERR_ARG, "mutation new_pos must be strictly increasing within a chromosome");
+            // equal new_pos happens: a deletion covers no haplotype position, so an edit right after it shares its new_pos
+            if (m > cell_off[k] && hs.new_pos[m] < hs.new_pos[m - 1]) throw Error(JK_ERR_ARG, "mutation new_pos must not decrease within a chromosome");
             if (smod >= 0 && have < (uint64_t)smod + 1) throw Error(JK_ERR_ARG, "mutation has fewer nucleotides than its size modifier needs");
             if (smod + 1 > 0x7fffffffLL) throw Error(JK_ERR_UNSUPPORTED, "insertion longer than 2^31 bases");
             nuc_len[m] = smod >= 0 ? (uint32_t)(smod + 1) : 0u;
@@ -1327,6 +1329,135 @@ int jk_hap_chrom_full(const jk_hap_set* hs, uint64_t hap, uint64_t chrom, char* 
         }
     });
 }
+
+// ---- mutation-table builder (host) ----
+struct jk_hap_builder {
+    uint64_t n_haps = 0, n_chroms = 0;
+    std::vector<std::string> chrom_names, hap_names;
+    std::string ref_name;
+    std::vector<const char*> seqs;
+    std::vector<uint64_t> lens;
+    std::vector<jk::HapCell> cells;          // [hap * n_chroms + chrom]
+    // flat view, rebuilt by jk_hap_builder_view
+    std::vector<const char*> v_chrom_names, v_hap_names;
+    std::vector<uint64_t> v_size, v_nmut, v_op, v_np, v_off;
+    std::string v_blob;
+};
+
+static jk_hap_builder* builder_shell(const jk_ref_genome* ref, uint64_t n_haps, const char* const* hap_names) {
+    if (!ref) throw Error(JK_ERR_ARG, "NULL reference genome");
+    std::unique_ptr<jk_hap_builder> b(new jk_hap_builder);
+    b->n_haps = n_haps;
+    b->n_chroms = ref->n_chroms;
+    b->ref_name = ref->name ? ref->name : "REF";
+    for (uint64_t c = 0; c < ref->n_chroms; c++) {
+        b->chrom_names.push_back(ref->chrom_names && ref->chrom_names[c] ? ref->chrom_names[c] : "chrom" + std::to_string(c));
+        b->seqs.push_back(ref->chrom_seqs[c]);
+        b->lens.push_back(ref->chrom_lens[c]);
+    }
+    // HapSet(ref, n) names haplotypes hap0.. (src/hap_classes.h:546-550)
+    for (uint64_t h = 0; h < n_haps; h++)
+        b->hap_names.push_back(hap_names && hap_names[h] ? hap_names[h] : "hap" + std::to_string(h));
+    b->cells.resize(n_haps * ref->n_chroms);
+    for (uint64_t h = 0; h < n_haps; h++)
+        for (uint64_t c = 0; c < ref->n_chroms; c++) {
+            jk::HapCell& cell = b->cells[h * ref->n_chroms + c];
+            cell.ref = ref->chrom_seqs[c];
+            cell.ref_len = cell.size = ref->chrom_lens[c];
+        }
+    return b.release();
+}
+
+int jk_hap_builder_new(const jk_ref_genome* ref, uint64_t n_haps, jk_hap_builder** out) {
+    return guarded([&] {
+        if (!out) throw Error(JK_ERR_ARG, "NULL output pointer");
+        *out = builder_shell(ref, n_haps, nullptr);
+    });
+}
+
+int jk_hap_builder_from(const jk_hap_set* hs, jk_hap_builder** out) {
+    return guarded([&] {
+        if (!hs || !out) throw Error(JK_ERR_ARG, "NULL haplotype set / output pointer");
+        if (hs->n_chroms != hs->ref.n_chroms) throw Error(JK_ERR_ARG, "haplotype set and reference differ in chromosome count");
+        std::unique_ptr<jk_hap_builder> b(builder_shell(&hs->ref, hs->n_haps, hs->hap_names));
+        uint64_t m = 0;
+        for (uint64_t k = 0; k < hs->n_haps * hs->n_chroms; k++) {
+            jk::HapCell& cell = b->cells[k];
+            cell.size = hs->chrom_size[k];
+            for (uint64_t i = 0; i < hs->n_mut[k]; i++, m++) {
+                cell.op.push_back(hs->old_pos[m]);
+                cell.np.push_back(hs->new_pos[m]);
+                cell.nt.emplace_back(hs->nuc_blob + hs->nuc_off[m], hs->nuc_blob + hs->nuc_off[m + 1]);
+            }
+        }
+        *out = b.release();
+    });
+}
+
+static jk::HapCell& builder_cell(jk_hap_builder* b, uint64_t hap, uint64_t chrom) {
+    if (!b) throw Error(JK_ERR_ARG, "NULL builder");
+    if (hap >= b->n_haps) throw Error(JK_ERR_ARG, "hap_ind out of range");
+    if (chrom >= b->n_chroms) throw Error(JK_ERR_ARG, "chrom_ind out of range");
+    return b->cells[hap * b->n_chroms + chrom];
+}
+
+// message of HapChrom::get_mut_ (src/hap_classes.cpp:731-735)
+static const char* const kNewPosMsg = "new_pos should never be >= the chromosome size. "
+    "Either re-calculate the chromosome size or closely examine new_pos.";
+
+int jk_add_substitution(jk_hap_builder* b, uint64_t hap, uint64_t chrom, char nucleo, uint64_t new_pos) {
+    return guarded([&] {
+        jk::HapCell& cell = builder_cell(b, hap, chrom);
+        if (new_pos >= cell.size || !cell.substitute(nucleo, new_pos)) throw Error(JK_ERR_ARG, kNewPosMsg);
+    });
+}
+
+int jk_add_insertion(jk_hap_builder* b, uint64_t hap, uint64_t chrom, const char* nucleos, uint64_t new_pos) {
+    return guarded([&] {
+        jk::HapCell& cell = builder_cell(b, hap, chrom);
+        if (!nucleos) throw Error(JK_ERR_ARG, "NULL nucleotides");
+        if (new_pos >= cell.size || !cell.insert(nucleos, new_pos)) throw Error(JK_ERR_ARG, kNewPosMsg);
+    });
+}
+
+int jk_add_deletion(jk_hap_builder* b, uint64_t hap, uint64_t chrom, uint64_t size, uint64_t new_pos) {
+    // size 0 or a position past the end is a silent no-op in the reference (src/hap_classes.cpp:297)
+    return guarded([&] { builder_cell(b, hap, chrom).remove(size, new_pos); });
+}
+
+int jk_hap_builder_view(jk_hap_builder* b, jk_hap_set* out) {
+    return guarded([&] {
+        if (!b || !out) throw Error(JK_ERR_ARG, "NULL builder / output pointer");
+        b->v_size.clear(); b->v_nmut.clear(); b->v_op.clear(); b->v_np.clear(); b->v_blob.clear();
+        b->v_off.assign(1, 0);
+        for (const jk::HapCell& cell : b->cells) {
+            b->v_size.push_back(cell.size);
+            b->v_nmut.push_back(cell.count());
+            b->v_op.insert(b->v_op.end(), cell.op.begin(), cell.op.end());
+            b->v_np.insert(b->v_np.end(), cell.np.begin(), cell.np.end());
+            for (const std::string& s : cell.nt) { b->v_blob += s; b->v_off.push_back(b->v_blob.size()); }
+        }
+        b->v_chrom_names.clear(); b->v_hap_names.clear();
+        for (const std::string& s : b->chrom_names) b->v_chrom_names.push_back(s.c_str());
+        for (const std::string& s : b->hap_names) b->v_hap_names.push_back(s.c_str());
+        out->n_haps = b->n_haps;
+        out->n_chroms = b->n_chroms;
+        out->hap_names = b->v_hap_names.data();
+        out->ref.n_chroms = b->n_chroms;
+        out->ref.chrom_names = b->v_chrom_names.data();
+        out->ref.chrom_seqs = b->seqs.data();
+        out->ref.chrom_lens = b->lens.data();
+        out->ref.name = b->ref_name.c_str();
+        out->chrom_size = b->v_size.data();
+        out->n_mut = b->v_nmut.data();
+        out->old_pos = b->v_op.data();
+        out->new_pos = b->v_np.data();
+        out->nuc_off = b->v_off.data();
+        out->nuc_blob = b->v_blob.c_str();
+    });
+}
+
+void jk_hap_builder_free(jk_hap_builder* b) { delete b; }
 
 void jk_eval_set_gamma(double shape, double scale) { g_eval_shape = shape; g_eval_scale = scale; }
 

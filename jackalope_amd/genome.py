@@ -134,6 +134,132 @@ class HapSet:
         return b"".join(out)
 
 
+class HapBuilder:
+    """Editable haplotype set: the write side of the reference's ``haplotypes`` R6 class
+    (/root/reference/R/aaa-classes.R:791-850, 886-893) over the native mutation-table builder
+    (``jk_hap_builder``; HapChrom::add_substitution/add_insertion/add_deletion,
+    /root/reference/src/hap_classes.cpp:295-509).  Indices and positions are 1-based like the R
+    methods; ``snapshot()`` gives the ``HapSet`` the sequencers take."""
+
+    _NTS = set("TCAGN")
+
+    def __init__(self, ref, n_haps=None, _from=None):
+        self.ref = ref
+        self._h = C.c_void_p()
+        L = _abi.lib()
+        if _from is not None:
+            v, keep = _from._view()
+            _abi.check(L.jk_hap_builder_from(C.byref(v), C.byref(self._h)))
+            self._n_haps = _from.n_haps()
+        else:
+            rv, keep = ref._view()
+            _abi.check(L.jk_hap_builder_new(C.byref(rv), int(n_haps), C.byref(self._h)))
+            self._n_haps = int(n_haps)
+        self._keep = keep          # the chromosome bytes are borrowed by the builder
+
+    @classmethod
+    def from_hapset(cls, hs):
+        return cls(hs.ref, _from=hs)
+
+    def close(self):
+        if self._h:
+            _abi.lib().jk_hap_builder_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def n_haps(self):
+        return self._n_haps
+
+    def n_chroms(self):
+        return self.ref.n_chroms()
+
+    def _raw_view(self):
+        v = _abi.HapSetView()
+        _abi.check(_abi.lib().jk_hap_builder_view(self._h, C.byref(v)))
+        return v
+
+    def sizes(self, hap_ind):
+        """Chromosome sizes of one haplotype (1-based), like haplotypes$sizes(hap_ind)."""
+        self._check_hap(hap_ind, "sizes")
+        v, nc = self._raw_view(), self.n_chroms()
+        return [int(v.chrom_size[(hap_ind - 1) * nc + c]) for c in range(nc)]
+
+    def _err(self, fun, arg, what):
+        # err_msg() of /root/reference/R/util.R:46-49
+        raise ValueError("\nFor the `%s` function in jackalope, argument `%s` must be %s." % (fun, arg, what))
+
+    def _check_hap(self, hap_ind, fun):
+        if not isinstance(hap_ind, (int, np.integer)) or not 1 <= hap_ind <= self._n_haps:
+            self._err(fun, "hap_ind", "integer in range [1, <# haplotypes>]")
+
+    def _check_pos(self, hap_ind, chrom_ind, pos, fun):
+        if not isinstance(chrom_ind, (int, np.integer)) or not 1 <= chrom_ind <= self.n_chroms():
+            self._err(fun, "chrom_ind", "integer in range [1, <# chromosomes>]")
+        self._check_hap(hap_ind, fun)
+        if not isinstance(pos, (int, np.integer)) or not 1 <= pos <= self.sizes(hap_ind)[chrom_ind - 1]:
+            self._err(fun, "pos", "integer in range [1, <chromosome size>]")
+
+    def add_sub(self, hap_ind, chrom_ind, pos, nt):
+        self._check_pos(hap_ind, chrom_ind, pos, "add_sub")
+        if not isinstance(nt, str) or len(nt) != 1:
+            self._err("add_sub", "nt", "a single character")
+        if nt not in self._NTS:
+            self._err("add_sub", "nt", 'one of "T", "C", "A", "G", or "N"')
+        _abi.check(_abi.lib().jk_add_substitution(self._h, hap_ind - 1, chrom_ind - 1, nt.encode(), pos - 1))
+        return self
+
+    def add_ins(self, hap_ind, chrom_ind, pos, nts):
+        self._check_pos(hap_ind, chrom_ind, pos, "add_ins")
+        if not isinstance(nts, str):
+            self._err("add_ins", "nts", "a single string")
+        if not set(nts) <= self._NTS:
+            self._err("add_ins", "nts", 'string containing only "T", "C", "A", "G", or "N"')
+        _abi.check(_abi.lib().jk_add_insertion(self._h, hap_ind - 1, chrom_ind - 1, nts.encode(), pos - 1))
+        return self
+
+    def add_del(self, hap_ind, chrom_ind, pos, n_nts):
+        self._check_pos(hap_ind, chrom_ind, pos, "add_del")
+        if not isinstance(n_nts, (int, np.integer)) or n_nts < 1:
+            self._err("add_del", "n_nts", "a single integer >= 1")
+        _abi.check(_abi.lib().jk_add_deletion(self._h, hap_ind - 1, chrom_ind - 1, int(n_nts), pos - 1))
+        return self
+
+    def chrom(self, hap_ind, chrom_ind):
+        """Full haplotype chromosome (1-based), like haplotypes$chrom()."""
+        self._check_hap(hap_ind, "chrom")
+        v = self._raw_view()
+        n = int(v.chrom_size[(hap_ind - 1) * self.n_chroms() + chrom_ind - 1])
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        _abi.check(_abi.lib().jk_hap_chrom_full(C.byref(v), hap_ind - 1, chrom_ind - 1, out.ctypes.data, n))
+        return out[:n].tobytes().decode()
+
+    def snapshot(self):
+        """Copy of the current tables as a HapSet."""
+        v = self._raw_view()
+        nh, nc = self._n_haps, self.n_chroms()
+        cells, m = [], 0
+        blob_len = int(v.nuc_off[sum(int(v.n_mut[k]) for k in range(nh * nc))])
+        blob = C.string_at(v.nuc_blob, blob_len)
+        for h in range(nh):
+            row = []
+            for c in range(nc):
+                k = h * nc + c
+                n = int(v.n_mut[k])
+                row.append({"chrom_size": int(v.chrom_size[k]),
+                            "old_pos": [int(v.old_pos[m + i]) for i in range(n)],
+                            "new_pos": [int(v.new_pos[m + i]) for i in range(n)],
+                            "nucleos": [blob[int(v.nuc_off[m + i]):int(v.nuc_off[m + i + 1])].decode() for i in range(n)]})
+                m += n
+            cells.append(row)
+        names = [v.hap_names[h].decode() for h in range(nh)]
+        return HapSet(self.ref, cells, names)
+
+
 def random_haplotypes(ref, n_haps, seed, sub_rate=1e-3, ins_rate=1e-4, del_rate=1e-4, mean_indel=3.0):
     """Synthetic mutation tables in the reference's canonical representation (stand-in for
     haps_phylo()/create_haplotypes(), which are out of scope): substitutions, insertions and deletions

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from helpers import job, first_diff, fastq_records
+from helpers import builder_haplotypes, job, first_diff, fastq_records
 from jackalope_amd.genome import random_haplotypes, HapSet
 
 pytestmark = pytest.mark.gpu
@@ -131,5 +131,14 @@ def test_sep_files(ja, O, tmp_path):
 def test_bad_tables_are_rejected(ja):
     ref = ja.synthetic_genome([1000], seed=33)
     bad = HapSet(ref, [[{"chrom_size": 1000, "old_pos": [10, 5], "new_pos": [10, 5], "nucleos": ["A", "C"]}]])
-    with pytest.raises(ja.JackalopeHipError, match="increasing"):
+    with pytest.raises(ja.JackalopeHipError, match="must not decrease"):
         ja.illumina(bad, None, 10, 150, True, n_threads=1, seed_words=ja.seed_words(1, 256), _session=True)
+
+
+def test_tables_from_the_mutation_builder(ja, O):
+    hs = builder_haplotypes(ja, [6000, 1500], 3, 1500, seed=40)
+    ties = sum(sum(1 for a, b in zip(cell["new_pos"], cell["new_pos"][1:]) if a == b) for row in hs.cells for cell in row)
+    assert ties > 0          # the case the device search must get right
+    check(ja, O, hs, 150, 4000, 16, job())
+    check(ja, O, hs, 100, 3001, 5, job(paired=False))
+    check(ja, O, hs, 150, 2000, 7, job(matepair=True, frag_mean=700.0, frag_sd=80.0))

@@ -4,7 +4,7 @@ structural only (tests/testthat/test-sequencer.R:285-319); they are restated her
 import numpy as np
 import pytest
 
-from helpers import first_diff, fastq_records
+from helpers import builder_haplotypes, first_diff, fastq_records
 from jackalope_amd.genome import random_haplotypes
 
 pytestmark = pytest.mark.gpu
@@ -81,6 +81,19 @@ def test_haplotypes(ja, O):
     o2, _, _ = O.pacbio_hap(hs, {}, hap_probs=[1.0, 1.0, 1.0], n_reads=120, n_threads=4, words=words)
     h2, _, _ = hip(ja, hs, 120, 4, words, {})
     assert h2 == o2
+
+
+def test_tables_from_the_mutation_builder(ja, O):
+    """Overlapping edits made by jk_add_*: merged deletions, trimmed insertions, records sharing a new_pos."""
+    hs = builder_haplotypes(ja, [60_000, 9_000], 2, 4000, seed=60)
+    T, n = 9, 300
+    words = ja.seed_words(4, hs.seed_budget(T))
+    pb = {"custom_read_lengths": [300, 1500, 4000]}
+    o, used_o, _ = O.pacbio_hap(hs, pb, hap_probs=[1.0, 1.0], n_reads=n, n_threads=T, words=words)
+    h, reads, used_h = hip(ja, hs, n, T, words, pb)
+    assert used_o == used_h
+    if h != o:
+        raise AssertionError("FASTQ differs at byte %d:\nHIP    %r\noracle %r" % first_diff(h, o))
 
 
 def test_lane_shards_and_files(ja, O, tmp_path):
