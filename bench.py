@@ -121,6 +121,81 @@ def pacbio_main(a):
     sess.close()
 
 
+def bgzf_main(a):
+    """Secondary line: the compressed sink.  The R1 FASTQ image of the headline workload (configs[1], 10 M pairs,
+    3.3 GB) is BGZF-compressed where it lies in HBM (jk_bgzf_deflate).  A step = one pass over that image."""
+    import ctypes as C
+    import torch
+    import jackalope_amd as ja
+    from jackalope_amd import _abi
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("the BGZF line is single-GPU in this round")
+    torch.cuda.set_device(local_rank)
+    genome = ja.synthetic_genome([int(a.genome_mbp * 1e6)], seed=2)
+    words = ja.seed_words(12345, 16 * a.lanes)
+    sess = ja.illumina(genome, None, 2 * a.pairs, 150, True, n_threads=a.lanes, seed_words=words, device=local_rank, _session=True)
+    sess.generate()
+    sizes, _ = sess.sizes()
+    n = int(sizes[0])
+    L = _abi.lib()
+    cap = int(L.jk_bgzf_bound(n))
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    src = sess.device_ptr(0)
+    out_bytes, ms = C.c_uint64(), C.c_double()
+
+    def step():
+        _abi.check(L.jk_bgzf_deflate(local_rank, src, n, dst.data_ptr(), cap, C.byref(out_bytes), C.byref(ms)))
+        return ms.value
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    for _ in range(a.steps):
+        dev_ms += step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    comp = int(out_bytes.value)
+    n_blocks = (n + 0xff00 - 1) // 0xff00
+    n_launch = (n_blocks + 8191) // 8192
+    alg = n + comp                                   # read the image once, write the compressed image once
+    kern_s = dev_ms / a.steps / 1e3
+    out = {"metric": "GB/s of FASTQ into BGZF (device sink)", "value": round(n * a.steps / elapsed / 1e9, 2), "unit": "GB/s",
+           "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "R1 FASTQ image of configs[1] (%d pairs PE150, %d bytes) compressed in HBM" % (a.pairs, n),
+                      "bgzf_blocks": n_blocks, "compressed_bytes": comp, "ratio": round(comp / n, 4)},
+           "roofline": {"bound": "hbm", "achieved": round(alg / kern_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "kernel": "bgzf_deflate_kernel (+ scan, gather)", "launches_per_step": n_launch,
+                        "kernel_ms": round(kern_s * 1e3 / n_launch, 3),
+                        "note": "achieved = (input + compressed bytes) / device time of all launches of a step; the "
+                                "slot scratch adds one write and one read of the compressed bytes on top"}}
+    if not a.no_cpu_baseline:
+        # what the reference does on the host (bgzf_write: zlib deflate of 0xff00-byte blocks), level 6, all cores
+        import zlib
+        from concurrent.futures import ThreadPoolExecutor
+        cores = min(os.cpu_count() or 1, 64)
+        sample_n = min(n, 0xff00 * 4096 * 4)
+        plain = sess.fetch(0)[:sample_n]
+
+        def one(off):
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            blk = plain[off:off + 0xff00]
+            zlib.crc32(blk)
+            return len(co.compress(blk) + co.flush()) + 26
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            tot = sum(ex.map(one, range(0, sample_n, 0xff00)))
+        dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(sample_n / dt / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
+                               "sample": "first %d bytes of the same image, zlib level 6 raw deflate per 0xff00-byte block "
+                                         "(what bgzf_write does) on %d threads, ratio %.4f (%.1f s)" % (sample_n, cores, tot / sample_n, dt)}
+    print(json.dumps(out))
+    sess.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,11 +206,14 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=100.0)
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = choose for about 15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["illumina", "pacbio"], default="illumina",
-                    help="illumina = the headline metric (BASELINE configs[1]); pacbio = configs[4]-style secondary line")
+    ap.add_argument("--workload", choices=["illumina", "pacbio", "bgzf"], default="illumina",
+                    help="illumina = the headline metric (BASELINE configs[1]); pacbio = configs[4]-style secondary line; "
+                         "bgzf = the device-side compressed sink on the headline workload's FASTQ")
     a = ap.parse_args()
     if a.workload == "pacbio":
         return pacbio_main(a)
+    if a.workload == "bgzf":
+        return bgzf_main(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -105,7 +105,7 @@ typedef struct jk_illumina_args {
     const char* out_prefix;           /* files <prefix>_R1.fq[, <prefix>_R2.fq] (src/hts.h:342-346) */
     int32_t sep_files;                /* hap only: one pair of files per haplotype (src/hts.h:512-552) */
     int32_t compress;                 /* 0 = plain, 1..9 = level; files get ".gz" appended (src/io.h) */
-    const char* comp_method;          /* "bgzip" (BGZF, default) or "gzip" */
+    const char* comp_method;          /* "bgzip" (BGZF made on the device, default), "bgzip-host" (BGZF, zlib on the host) or "gzip" */
     uint64_t n_reads;
     double prob_dup;
     uint64_t n_threads;               /* number of lanes, see header comment */
@@ -205,6 +205,17 @@ int jk_reads_per_group(uint64_t n_reads, const double* probs, uint64_t n,       
                        jk_seed_source* seeds, uint64_t* out);
 void jk_alias_build(const double* probs, uint64_t n, double* Prob, uint64_t* Alias);   /* src/alias_sampler.h:68-106 */
 int jk_hap_chrom_full(const jk_hap_set* haps, uint64_t hap, uint64_t chrom, char* out, uint64_t cap); /* src/hap_classes.cpp:80-116 (host) */
+
+/* BGZF compression of a byte image that is already in device memory (second
+ * "next" row): the device-side replacement of FileBGZF / bgzip_file (src/io.h:150-236, src/hts.h:140-180).
+ * d_src (16-byte aligned) and d_dst are DEVICE pointers; d_dst needs jk_bgzf_bound(n) bytes.  The result
+ * is a complete BGZF file image (blocks of <= 0xff00 input bytes, then the end-of-file block): one
+ * dynamic-Huffman DEFLATE block of literals per BGZF block, or a stored block where that is smaller.
+ * jk_session_write uses it when comp_method is "bgzip"; "bgzip-host" deflates the same blocks with zlib
+ * on the host at the requested level, "gzip" writes one gzip stream on the host (FileGZ, src/io.h:58-147).
+ * ms (may be NULL) receives the device time of the compression kernels. */
+uint64_t jk_bgzf_bound(uint64_t n);
+int jk_bgzf_deflate(int device, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_bytes, double* ms);
 
 /* Mutation tables, write side (first "next" row): the haplotype objects the
  * sequencers read are built by these three edits.  A builder is the reference's XPtr<HapSet>; the

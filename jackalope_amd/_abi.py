@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libjackalope_hip.so")
+LIB_PATH = os.environ.get("JK_HIP_LIB") or os.path.join(_HERE, "csrc", "libjackalope_hip.so")   # JK_HIP_LIB: kernel-variant experiments
 
 JK_OK = 0
 JK_ERR_ARG, JK_ERR_UNSUPPORTED, JK_ERR_DEVICE, JK_ERR_IO, JK_ERR_SEEDS, JK_ERR_ABORTED = 1, 2, 3, 4, 5, 6
@@ -110,6 +110,7 @@ EXPORTS = [
     "jk_host_eval", "jk_dev_eval", "jk_eval_set_gamma", "jk_x87_one_minus",
     "jk_hap_builder_new", "jk_hap_builder_from", "jk_add_substitution", "jk_add_insertion", "jk_add_deletion",
     "jk_hap_builder_view", "jk_hap_builder_free",
+    "jk_bgzf_bound", "jk_bgzf_deflate",
 ]
 
 _lib = None
@@ -168,6 +169,10 @@ def lib():
     L.jk_hap_builder_view.argtypes = [C.c_void_p, C.POINTER(HapSetView)]
     L.jk_hap_builder_free.argtypes = [C.c_void_p]
     L.jk_hap_builder_free.restype = None
+    L.jk_bgzf_bound.restype = C.c_uint64
+    L.jk_bgzf_bound.argtypes = [C.c_uint64]
+    L.jk_bgzf_deflate.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_double)]
     L.jk_host_eval.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     L.jk_dev_eval.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     L.jk_eval_set_gamma.argtypes = [C.c_double, C.c_double]

@@ -20,6 +20,7 @@
 #include "jk_math2.h"
 #include "jk_nmath.h"
 #include "jk_pacbio_kernel.h"
+#include "jk_bgzf_kernel.h"
 
 namespace jk {
 
@@ -86,6 +87,7 @@ struct jk_session {
     bool hap = false;
     int compress = 0;          // 0 = plain FASTQ, 1..9 = compression level
     bool bgzip = true;         // comp_method: "bgzip" (BGZF blocks) or "gzip"
+    bool host_deflate = false; // comp_method "bgzip-host": BGZF blocks deflated by zlib on the host at level `compress`
     bool pacbio = false;
     PacbioKernelParams kpb{};
     DevBuf d_len_thresh, d_len_alias, d_lens, d_thr_tab, d_pass_tab, d_ev2;
@@ -157,8 +159,9 @@ static void set_compression(jk_session& s, int compress, const char* comp_method
     if (compress < 0 || compress > 9) throw Error(JK_ERR_ARG, "\nInvalid bgzip compress level of " + std::to_string(compress) + ". It must be in range [0,9].");
     s.compress = compress;
     const std::string m = comp_method ? comp_method : "bgzip";
-    if (compress > 0 && m != "gzip" && m != "bgzip") throw Error(JK_ERR_ARG, "\nUnrecognized compression method.");
+    if (compress > 0 && m != "gzip" && m != "bgzip" && m != "bgzip-host") throw Error(JK_ERR_ARG, "\nUnrecognized compression method.");
     s.bgzip = (m != "gzip");
+    s.host_deflate = (m == "bgzip-host");
 }
 
 static inline uint8_t encode_base(char c) { return c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : 4; }
@@ -948,33 +951,158 @@ static void bgzf_compress_block(const uint8_t* src, size_t n, int level, std::ve
     out.resize(start + total);
 }
 
+// ---- BGZF on the device (jk_bgzf_kernel.h) -----------------------------------------------------------
+static const uint8_t kBgzfEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+static uint64_t bgzf_bound(uint64_t n) {
+    const uint64_t nb = (n + BGZF_BLOCK_IN - 1) / BGZF_BLOCK_IN;
+    return n + nb * 31 + sizeof(kBgzfEof);          // every block stored: 18 + 5 + 8 bytes around its input
+}
+
+struct BgzfDeviceTables { DevBuf crc, x512, x8; };
+static BgzfTables bgzf_tables(int device) {
+    static std::vector<std::unique_ptr<BgzfDeviceTables>> per_device(64);
+    if (device < 0 || device >= 64) throw Error(JK_ERR_ARG, "bad device ordinal");
+    if (!per_device[device]) {
+        std::vector<uint32_t> crc(4 * 256), x512(1024), x8(64);
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? CRC_POLY : 0u);
+            crc[i] = c;
+        }
+        for (int k = 1; k < 4; k++)                 // slicing tables: one more zero byte appended per level
+            for (uint32_t i = 0; i < 256; i++) crc[k * 256 + i] = (crc[(k - 1) * 256 + i] >> 8) ^ crc[crc[(k - 1) * 256 + i] & 0xffu];
+        uint32_t xb = 0x80000000u;                   // x^0
+        for (int k = 0; k < 8; k++) xb = crc_mulmod(xb, 0x40000000u);     // x^8
+        x8[0] = 0x80000000u;
+        for (int r = 1; r < 64; r++) x8[r] = crc_mulmod(x8[r - 1], xb);
+        const uint32_t step = crc_mulmod(x8[63], xb);                    // x^512
+        x512[0] = 0x80000000u;
+        for (int j = 1; j < 1024; j++) x512[j] = crc_mulmod(x512[j - 1], step);
+        std::unique_ptr<BgzfDeviceTables> t(new BgzfDeviceTables);
+        t->crc.upload(crc); t->x512.upload(x512); t->x8.upload(x8);
+        per_device[device] = std::move(t);
+    }
+    BgzfTables T;
+    T.crc_tab = per_device[device]->crc.as<uint32_t>();
+    T.x512 = per_device[device]->x512.as<uint32_t>();
+    T.x8 = per_device[device]->x8.as<uint32_t>();
+    return T;
+}
+
+// d_src[0..n) -> complete BGZF file image (blocks + end-of-file block) at d_dst; returns its size.
+// Works through the input in groups of blocks so that the slot scratch stays at 512 MiB.
+static uint64_t bgzf_deflate_device(int device, hipStream_t stream, const uint8_t* d_src, uint64_t n, uint8_t* d_dst,
+                                    uint64_t cap, double* ms) {
+    if (reinterpret_cast<uintptr_t>(d_src) & 15u) throw Error(JK_ERR_ARG, "BGZF input must be 16-byte aligned");
+    if (cap < bgzf_bound(n)) throw Error(JK_ERR_ARG, "BGZF destination smaller than jk_bgzf_bound()");
+    const BgzfTables T = bgzf_tables(device);
+    const uint64_t n_blocks = (n + BGZF_BLOCK_IN - 1) / BGZF_BLOCK_IN;
+    const uint64_t GROUP = 8192;
+    const uint64_t n_groups = (n_blocks + GROUP - 1) / GROUP;
+    DevBuf slots, sizes, offs, sums, base;
+    const uint64_t g_blocks = std::min<uint64_t>(GROUP, std::max<uint64_t>(n_blocks, 1));
+    slots.alloc(g_blocks * BGZF_SLOT);
+    sizes.alloc(g_blocks * 8); offs.alloc(g_blocks * 8);
+    sums.alloc(((g_blocks + SCAN_BLOCK - 1) / SCAN_BLOCK) * 8);
+    base.alloc((n_groups + 1) * 8);
+    JK_HIP(hipMemsetAsync(base.p, 0, (n_groups + 1) * 8, stream));
+    hipEvent_t e0, e1;
+    JK_HIP(hipEventCreate(&e0)); JK_HIP(hipEventCreate(&e1));
+    JK_HIP(hipEventRecord(e0, stream));
+    for (uint64_t g = 0; g < n_groups; g++) {
+        const uint64_t b0 = g * GROUP;
+        const uint32_t nb = (uint32_t)std::min<uint64_t>(GROUP, n_blocks - b0);
+        const uint64_t off = b0 * BGZF_BLOCK_IN;
+        hipLaunchKernelGGL(bgzf_deflate_kernel, dim3(nb), dim3(BGZF_THREADS), 0, stream, d_src + off, n - off,
+                           slots.as<uint8_t>(), sizes.as<uint64_t>(), T);
+        const uint32_t nsb = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        hipLaunchKernelGGL(scan_block_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, stream, sizes.as<uint64_t>(), offs.as<uint64_t>(),
+                           sums.as<uint64_t>(), nb);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, stream, sums.as<uint64_t>(), nsb, base.as<uint64_t>() + g);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, stream, offs.as<uint64_t>(), sums.as<uint64_t>(), nb);
+        hipLaunchKernelGGL(bgzf_gather_kernel, dim3(nb), dim3(256), 0, stream, slots.as<uint8_t>(), sizes.as<uint64_t>(),
+                           offs.as<uint64_t>(), d_dst, base.as<uint64_t>() + g);
+    }
+    JK_HIP(hipGetLastError());
+    JK_HIP(hipEventRecord(e1, stream));
+    uint64_t total = 0;
+    JK_HIP(hipMemcpyAsync(&total, base.as<uint64_t>() + n_groups, 8, hipMemcpyDeviceToHost, stream));
+    JK_HIP(hipStreamSynchronize(stream));
+    JK_HIP(hipMemcpy(d_dst + total, kBgzfEof, sizeof(kBgzfEof), hipMemcpyHostToDevice));
+    if (ms) { float t = 0; JK_HIP(hipEventElapsedTime(&t, e0, e1)); *ms = t; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return total + sizeof(kBgzfEof);
+}
+
+// Device image -> host consumer through two pinned buffers: the copy of piece k+1 runs while `sink`
+// works on piece k (file write, zlib).  `piece` is a whole number of BGZF input blocks.
+template <typename Sink>
+static void stream_to_host(const uint8_t* d_src, uint64_t n, size_t piece, Sink&& sink) {
+    struct Pinned {
+        void* p[2] = {nullptr, nullptr};
+        hipStream_t st = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        ~Pinned() {
+            for (int k = 0; k < 2; k++) { if (p[k]) (void)hipHostFree(p[k]); if (ev[k]) (void)hipEventDestroy(ev[k]); }
+            if (st) (void)hipStreamDestroy(st);
+        }
+    } P;
+    if (n == 0) return;
+    piece = (size_t)std::min<uint64_t>(piece, n);
+    JK_HIP(hipStreamCreateWithFlags(&P.st, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) { JK_HIP(hipHostMalloc(&P.p[k], piece, hipHostMallocDefault)); JK_HIP(hipEventCreate(&P.ev[k])); }
+    const uint64_t n_pieces = (n + piece - 1) / piece;
+    auto issue = [&](uint64_t k) {
+        const uint64_t off = k * piece;
+        JK_HIP(hipMemcpyAsync(P.p[k & 1], d_src + off, (size_t)std::min<uint64_t>(piece, n - off), hipMemcpyDeviceToHost, P.st));
+        JK_HIP(hipEventRecord(P.ev[k & 1], P.st));
+    };
+    issue(0);
+    for (uint64_t k = 0; k < n_pieces; k++) {
+        JK_HIP(hipEventSynchronize(P.ev[k & 1]));
+        if (k + 1 < n_pieces) issue(k + 1);
+        sink(static_cast<const uint8_t*>(P.p[k & 1]), (size_t)std::min<uint64_t>(piece, n - k * piece));
+    }
+}
+
 static void write_files(const jk_session& s) {
     if (!s.generated) throw Error(JK_ERR_ARG, "jk_session_write before jk_session_generate");
     const size_t CH = BGZF_IN * 1024;                     // 66.8 MB, a whole number of BGZF blocks
-    std::vector<uint8_t> buf(CH);
     const unsigned n_thr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     for (uint32_t e = 0; e < s.n_ends; e++) {
         std::string fn = s.out_prefix + "_R" + std::to_string(e + 1) + ".fq";
         if (s.compress > 0) fn += ".gz";
-        FILE* f = nullptr; gzFile gz = nullptr;
+        struct Files {
+            FILE* f = nullptr; gzFile gz = nullptr;
+            ~Files() { if (f) std::fclose(f); if (gz) gzclose(gz); }
+        } F;
         if (s.compress > 0 && !s.bgzip) {
             const std::string mode = "wb" + std::to_string(s.compress);
-            gz = gzopen(fn.c_str(), mode.c_str());
-            if (!gz) throw Error(JK_ERR_IO, "gzopen of " + fn + " failed.\n");
+            F.gz = gzopen(fn.c_str(), mode.c_str());
+            if (!F.gz) throw Error(JK_ERR_IO, "gzopen of " + fn + " failed.\n");
         } else {
-            f = std::fopen(fn.c_str(), "wb");
-            if (!f) throw Error(JK_ERR_IO, "Unable to open file " + fn + ".\n");
+            F.f = std::fopen(fn.c_str(), "wb");
+            if (!F.f) throw Error(JK_ERR_IO, "Unable to open file " + fn + ".\n");
         }
-        auto fail = [&](int code, const std::string& msg) { if (f) std::fclose(f); if (gz) gzclose(gz); throw Error(code, msg); };
-        for (uint64_t off = 0; off < s.bytes[e]; off += CH) {
-            const size_t n = (size_t)std::min<uint64_t>(CH, s.bytes[e] - off);
-            hipError_t he = hipMemcpy(buf.data(), s.d_out[e].as<uint8_t>() + off, n, hipMemcpyDeviceToHost);
-            if (he != hipSuccess) fail(JK_ERR_DEVICE, hipGetErrorString(he));
-            if (s.compress == 0) {
-                if (std::fwrite(buf.data(), 1, n, f) != n) fail(JK_ERR_IO, "short write to " + fn);
-            } else if (!s.bgzip) {
-                if (gzwrite(gz, buf.data(), (unsigned)n) != (int)n) fail(JK_ERR_IO, "gzwrite to " + fn + " failed");
-            } else {
+        auto put = [&](const uint8_t* p, size_t n) {
+            if (std::fwrite(p, 1, n, F.f) != n) throw Error(JK_ERR_IO, "short write to " + fn);
+        };
+        const uint8_t* d_img = s.d_out[e].as<uint8_t>();
+        if (s.compress == 0) {
+            stream_to_host(d_img, s.bytes[e], CH, put);
+        } else if (!s.bgzip) {
+            stream_to_host(d_img, s.bytes[e], CH, [&](const uint8_t* p, size_t n) {
+                if (gzwrite(F.gz, p, (unsigned)n) != (int)n) throw Error(JK_ERR_IO, "gzwrite to " + fn + " failed");
+            });
+        } else if (!s.host_deflate) {
+            // BGZF blocks made on the device; only the compressed image crosses the host link
+            DevBuf comp;
+            comp.alloc(bgzf_bound(s.bytes[e]));
+            const uint64_t n_comp = bgzf_deflate_device(s.device, s.stream, d_img, s.bytes[e], comp.as<uint8_t>(), comp.n, nullptr);
+            stream_to_host(comp.as<uint8_t>(), n_comp, CH, put);
+        } else {
+            stream_to_host(d_img, s.bytes[e], CH, [&](const uint8_t* buf, size_t n) {
                 const size_t n_blocks = (n + BGZF_IN - 1) / BGZF_IN;
                 std::vector<std::vector<uint8_t>> parts(n_thr);
                 std::vector<std::string> errs(n_thr);
@@ -983,22 +1111,19 @@ static void write_files(const jk_session& s) {
                     try {
                         const size_t b0 = n_blocks * t / n_thr, b1 = n_blocks * (t + 1) / n_thr;
                         for (size_t b = b0; b < b1; b++)
-                            bgzf_compress_block(buf.data() + b * BGZF_IN, std::min(BGZF_IN, n - b * BGZF_IN), s.compress, parts[t]);
+                            bgzf_compress_block(buf + b * BGZF_IN, std::min(BGZF_IN, n - b * BGZF_IN), s.compress, parts[t]);
                     } catch (const std::exception& ex) { errs[t] = ex.what(); }
                 });
                 for (std::thread& th : pool) th.join();
                 for (unsigned t = 0; t < n_thr; t++) {
-                    if (!errs[t].empty()) fail(JK_ERR_IO, errs[t]);
-                    if (!parts[t].empty() && std::fwrite(parts[t].data(), 1, parts[t].size(), f) != parts[t].size()) fail(JK_ERR_IO, "short write to " + fn);
+                    if (!errs[t].empty()) throw Error(JK_ERR_IO, errs[t]);
+                    if (!parts[t].empty()) put(parts[t].data(), parts[t].size());
                 }
-            }
+            });
+            put(kBgzfEof, sizeof(kBgzfEof));
         }
-        if (s.compress > 0 && s.bgzip) {
-            static const uint8_t eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (std::fwrite(eof_block, 1, 28, f) != 28) fail(JK_ERR_IO, "short write to " + fn);
-        }
-        if (f && std::fclose(f) != 0) throw Error(JK_ERR_IO, "error closing " + fn);
-        if (gz && gzclose(gz) != Z_OK) throw Error(JK_ERR_IO, "error closing " + fn);
+        if (F.f) { FILE* f = F.f; F.f = nullptr; if (std::fclose(f) != 0) throw Error(JK_ERR_IO, "error closing " + fn); }
+        if (F.gz) { gzFile g = F.gz; F.gz = nullptr; if (gzclose(g) != Z_OK) throw Error(JK_ERR_IO, "error closing " + fn); }
     }
 }
 
@@ -1458,6 +1583,16 @@ int jk_hap_builder_view(jk_hap_builder* b, jk_hap_set* out) {
 }
 
 void jk_hap_builder_free(jk_hap_builder* b) { delete b; }
+
+uint64_t jk_bgzf_bound(uint64_t n) { return bgzf_bound(n); }
+
+int jk_bgzf_deflate(int device, const void* d_src, uint64_t n, void* d_dst, uint64_t cap, uint64_t* out_bytes, double* ms) {
+    return guarded([&] {
+        if ((n && !d_src) || !d_dst || !out_bytes) throw Error(JK_ERR_ARG, "NULL pointer");
+        JK_HIP(hipSetDevice(device));
+        *out_bytes = bgzf_deflate_device(device, nullptr, static_cast<const uint8_t*>(d_src), n, static_cast<uint8_t*>(d_dst), cap, ms);
+    });
+}
 
 void jk_eval_set_gamma(double shape, double scale) { g_eval_shape = shape; g_eval_scale = scale; }
 

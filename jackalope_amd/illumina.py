@@ -68,7 +68,7 @@ def check_illumina_args(obj, n_reads, read_length, paired, frag_mean, frag_sd, m
     if profile1 is not None and profile2 is None and paired:
         raise ValueError("\nFor the function `illumina`, if you provide a custom profile for read 1 and want "
                          "paired-end reads, you must also provide one for read 2.")
-    if comp_method not in ("gzip", "bgzip"):
+    if comp_method not in ("gzip", "bgzip", "bgzip-host"):     # "bgzip-host": this library's zlib-on-the-host variant
         _err("comp_method", '"gzip" or "bgzip"')
     if not (isinstance(compress, (bool, np.bool_)) or (_is_num(compress, 1, 9) and int(compress) == compress)):
         _err("compress", "a single logical or integer from 1 to 9")

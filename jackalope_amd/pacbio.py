@@ -44,7 +44,7 @@ def check_pacbio_args(obj, n_reads, haplotype_probs, sep_files, compress, comp_m
     for nm, v in (("sep_files", sep_files), ("show_progress", show_progress)):
         if not isinstance(v, (bool, np.bool_)):
             _err(nm, "a single logical")
-    if comp_method not in ("gzip", "bgzip"):
+    if comp_method not in ("gzip", "bgzip", "bgzip-host"):     # "bgzip-host": this library's zlib-on-the-host variant
         _err("comp_method", '"gzip" or "bgzip"')
     if custom_read_lengths is not None:
         crl = np.asarray(custom_read_lengths, dtype=np.float64)
