@@ -196,6 +196,58 @@ def bgzf_main(a):
     sess.close()
 
 
+def create_genome_main(a):
+    """Secondary line: create_genome() on the device -- BASELINE configs[2]'s 3 Gbp reference (24 chromosomes of
+    125 Mbp, equal base frequencies) made in HBM.  A step = one whole genome."""
+    import torch
+    import jackalope_amd as ja
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("the create_genome line is single-GPU in this round")
+    torch.cuda.set_device(local_rank)
+    n_chroms, chrom_len = 24, int(125e6)
+    words = ja.seed_words(12345, 8)
+
+    def step():
+        g = ja.create_genome(n_chroms, chrom_len, 0, n_threads=1, seed_words=words, device=local_rank)
+        ms = g.kernel_ms()
+        g.close()
+        return ms
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    for _ in range(a.steps):
+        dev_ms += step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    bases = n_chroms * chrom_len
+    kern_s = dev_ms / a.steps / 1e3
+    out = {"metric": "Gbases/sec of create_genome (3 Gbp, 24 chromosomes)", "value": round(bases * a.steps / elapsed / 1e9, 2),
+           "unit": "Gbases/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "config": {"workload": "create_genome(24, 125e6, len_sd = 0, pi_tcag = 1/4 each, n_threads = 1): the reference "
+                                  "genome of configs[2..3]", "bases": bases},
+           "roofline": {"bound": "hbm", "achieved": round(bases / kern_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(bases / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "create_genome_kernel",
+                        "launches_per_step": 1, "kernel_ms": round(kern_s * 1e3, 3),
+                        "note": "1 byte written per base; integer-ALU bound: 2 pcg64 outputs per base (%.3g outputs/s "
+                                "against the measured 1.38e12/s ceiling)" % (2 * bases / kern_s)}}
+    if not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        cores = min(os.cpu_count() or 1, 64)
+        sample_len = int(400e6)
+        t1 = time.perf_counter()
+        O.create_genome(1, float(sample_len), 0.0, [0.25] * 4, 1, words)
+        dt = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(sample_len / dt / 1e9, 4), "unit": "Gbases/sec", "cores": 1, "kind": "port",
+                               "sample": "one %d-base chromosome by the oracle on 1 thread, as the reference runs with its default "
+                                         "n_threads = 1 (one engine is a sequential chain; %d host cores idle) (%.1f s)" % (sample_len, cores - 1, dt)}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,7 +258,7 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=100.0)
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = choose for about 15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["illumina", "pacbio", "bgzf"], default="illumina",
+    ap.add_argument("--workload", choices=["illumina", "pacbio", "bgzf", "create_genome"], default="illumina",
                     help="illumina = the headline metric (BASELINE configs[1]); pacbio = configs[4]-style secondary line; "
                          "bgzf = the device-side compressed sink on the headline workload's FASTQ")
     a = ap.parse_args()
@@ -214,6 +266,8 @@ def main():
         return pacbio_main(a)
     if a.workload == "bgzf":
         return bgzf_main(a)
+    if a.workload == "create_genome":
+        return create_genome_main(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -57,6 +57,7 @@ typedef struct jk_ref_genome {
     const char* const* chrom_seqs;    /* RefChrom::nucleos, chrom_lens[i] bytes, need not be NUL-terminated */
     const uint64_t* chrom_lens;
     const char* name;                 /* RefGenome::name, "REF" (src/ref_classes.h:138); NULL = "REF" */
+    int32_t seqs_on_device;           /* 0: chrom_seqs are host pointers; 1: device pointers (jk_genome_view) */
 } jk_ref_genome;
 
 /* View of a HapSet (src/hap_classes.h:500-611): for haplotype h and chromosome c, cell = h*n_chroms+c.
@@ -205,6 +206,26 @@ int jk_reads_per_group(uint64_t n_reads, const double* probs, uint64_t n,       
                        jk_seed_source* seeds, uint64_t* out);
 void jk_alias_build(const double* probs, uint64_t n, double* Prob, uint64_t* Alias);   /* src/alias_sampler.h:68-106 */
 int jk_hap_chrom_full(const jk_hap_set* haps, uint64_t hap, uint64_t chrom, char* out, uint64_t cap); /* src/hap_classes.cpp:80-116 (host) */
+/* pcg64 seeded from 8 words (src/pcg.h:48-85), jumped `steps` outputs ahead (engine::advance,
+ * inst/include/pcg/pcg_random.hpp:419-434), then n outputs: the jump tables of jk_create_genome (host) */
+void jk_pcg_advance_outputs(const uint32_t* words8, uint64_t steps, uint64_t n, uint64_t* out);
+
+/* create_genome (third "next" row): create_genome_cpp / create_chromosomes_
+ * (src/create_sequences.cpp:59-169) with the same arguments -- n_chroms chromosomes "chrom0".., lengths
+ * from a gamma distribution with the given mean and sd (all = len_mean when len_sd is 0), bases drawn
+ * with equilibrium frequencies pi_tcag[T,C,A,G]; n_threads engines, chromosomes dealt to them in
+ * contiguous blocks as `omp for schedule(static)` does.  Seeds: 8 words per thread (mt_seeds,
+ * src/pcg.h:63-71).  The genome is made in device memory and stays there: jk_genome_view gives a
+ * jk_ref_genome whose chrom_seqs are device pointers (seqs_on_device = 1) for jk_illumina_ref /
+ * jk_pacbio_ref; jk_genome_fetch copies one chromosome to the host.  The view borrows from the handle. */
+typedef struct jk_genome jk_genome;
+int jk_create_genome(uint64_t n_chroms, double len_mean, double len_sd, const double* pi_tcag, uint64_t n_threads,
+                     jk_seed_source* seeds, int device, jk_genome** out);
+int jk_genome_view(jk_genome* g, jk_ref_genome* view);
+int jk_genome_fetch(const jk_genome* g, uint64_t chrom, char* dst, uint64_t cap);
+uint64_t jk_genome_seed_words_used(const jk_genome* g);
+double jk_genome_ms(const jk_genome* g);          /* device milliseconds of the generating kernel */
+void jk_genome_free(jk_genome* g);
 
 /* BGZF compression of a byte image that is already in device memory (second
  * "next" row): the device-side replacement of FileBGZF / bgzip_file (src/io.h:150-236, src/hts.h:140-180).

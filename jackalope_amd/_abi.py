@@ -28,7 +28,8 @@ class RefGenomeView(C.Structure):
                 ("chrom_names", C.POINTER(C.c_char_p)),
                 ("chrom_seqs", C.POINTER(C.c_void_p)),
                 ("chrom_lens", C.POINTER(C.c_uint64)),
-                ("name", C.c_char_p)]
+                ("name", C.c_char_p),
+                ("seqs_on_device", C.c_int32)]
 
 
 class HapSetView(C.Structure):
@@ -111,6 +112,7 @@ EXPORTS = [
     "jk_hap_builder_new", "jk_hap_builder_from", "jk_add_substitution", "jk_add_insertion", "jk_add_deletion",
     "jk_hap_builder_view", "jk_hap_builder_free",
     "jk_bgzf_bound", "jk_bgzf_deflate",
+    "jk_pcg_advance_outputs", "jk_create_genome", "jk_genome_view", "jk_genome_fetch", "jk_genome_seed_words_used", "jk_genome_ms", "jk_genome_free",
 ]
 
 _lib = None
@@ -169,6 +171,18 @@ def lib():
     L.jk_hap_builder_view.argtypes = [C.c_void_p, C.POINTER(HapSetView)]
     L.jk_hap_builder_free.argtypes = [C.c_void_p]
     L.jk_hap_builder_free.restype = None
+    L.jk_create_genome.argtypes = [C.c_uint64, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_uint64,
+                                   C.POINTER(SeedSource), C.c_int, C.POINTER(C.c_void_p)]
+    L.jk_pcg_advance_outputs.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.jk_pcg_advance_outputs.restype = None
+    L.jk_genome_view.argtypes = [C.c_void_p, C.POINTER(RefGenomeView)]
+    L.jk_genome_fetch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    L.jk_genome_seed_words_used.restype = C.c_uint64
+    L.jk_genome_seed_words_used.argtypes = [C.c_void_p]
+    L.jk_genome_ms.restype = C.c_double
+    L.jk_genome_ms.argtypes = [C.c_void_p]
+    L.jk_genome_free.argtypes = [C.c_void_p]
+    L.jk_genome_free.restype = None
     L.jk_bgzf_bound.restype = C.c_uint64
     L.jk_bgzf_bound.argtypes = [C.c_uint64]
     L.jk_bgzf_deflate.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),

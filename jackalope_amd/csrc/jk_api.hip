@@ -21,6 +21,7 @@
 #include "jk_nmath.h"
 #include "jk_pacbio_kernel.h"
 #include "jk_bgzf_kernel.h"
+#include "jk_genome_kernel.h"
 
 namespace jk {
 
@@ -139,7 +140,8 @@ static void upload_genome(jk_session& s, const jk_ref_genome& g, const char* blo
     JK_HIP(hipMemset(s.d_seq.p, 'N', total));
     if (blob_len) JK_HIP(hipMemcpy(s.d_seq.as<uint8_t>() + s.nuc_base, blob_bytes, blob_len, hipMemcpyHostToDevice));
     for (uint64_t i = 0; i < g.n_chroms; i++)
-        if (len[i]) JK_HIP(hipMemcpy(s.d_seq.as<uint8_t>() + off[i], g.chrom_seqs[i], len[i], hipMemcpyHostToDevice));
+        if (len[i]) JK_HIP(hipMemcpy(s.d_seq.as<uint8_t>() + off[i], g.chrom_seqs[i], len[i],
+                                     g.seqs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     // T,C,A,G -> 0..3, everything else -> 4 (what nt_map / cmp_map of the reference distinguish)
     DevBuf bad; bad.alloc(4);
     JK_HIP(hipMemset(bad.p, 0, 4));
@@ -1438,6 +1440,7 @@ int jk_hap_chrom_full(const jk_hap_set* hs, uint64_t hap, uint64_t chrom, char* 
         const uint64_t m1 = m0 + hs->n_mut[cell];
         const uint64_t size = hs->chrom_size[cell], ref_len = hs->ref.chrom_lens[chrom];
         if (cap < size) throw Error(JK_ERR_ARG, "destination too small");
+        if (hs->ref.seqs_on_device) throw Error(JK_ERR_UNSUPPORTED, "jk_hap_chrom_full reads the reference on the host; this one is in device memory");
         const char* ref = hs->ref.chrom_seqs[chrom];
         uint64_t pos = 0;
         const uint64_t first = m0 < m1 ? hs->new_pos[m0] : size;
@@ -1471,6 +1474,7 @@ struct jk_hap_builder {
 
 static jk_hap_builder* builder_shell(const jk_ref_genome* ref, uint64_t n_haps, const char* const* hap_names) {
     if (!ref) throw Error(JK_ERR_ARG, "NULL reference genome");
+    if (ref->seqs_on_device) throw Error(JK_ERR_UNSUPPORTED, "the mutation-table builder reads reference bases on the host; this genome is in device memory (fetch it first)");
     std::unique_ptr<jk_hap_builder> b(new jk_hap_builder);
     b->n_haps = n_haps;
     b->n_chroms = ref->n_chroms;
@@ -1573,6 +1577,7 @@ int jk_hap_builder_view(jk_hap_builder* b, jk_hap_set* out) {
         out->ref.chrom_seqs = b->seqs.data();
         out->ref.chrom_lens = b->lens.data();
         out->ref.name = b->ref_name.c_str();
+        out->ref.seqs_on_device = 0;
         out->chrom_size = b->v_size.data();
         out->n_mut = b->v_nmut.data();
         out->old_pos = b->v_op.data();
@@ -1583,6 +1588,155 @@ int jk_hap_builder_view(jk_hap_builder* b, jk_hap_set* out) {
 }
 
 void jk_hap_builder_free(jk_hap_builder* b) { delete b; }
+
+// ---- create_genome (src/create_sequences.cpp:59-169) on the device ------------------------------
+struct jk_genome {
+    int device = 0;
+    DevBuf seq;
+    std::vector<uint64_t> off, len;
+    std::vector<std::string> names;
+    std::vector<const char*> v_names, v_seqs;
+    uint64_t seed_words_used = 0;
+    double ms = 0;
+};
+
+int jk_create_genome(uint64_t n_chroms, double len_mean, double len_sd, const double* pi_tcag, uint64_t n_threads,
+                     jk_seed_source* seeds, int device, jk_genome** out) {
+    return guarded([&] {
+        if (!out || !pi_tcag || !seeds) throw Error(JK_ERR_ARG, "NULL pointer");
+        if (n_chroms == 0 || n_chroms > 0xffffffffULL) throw Error(JK_ERR_ARG, "n_chroms must be in [1, 2^32)");
+        if (!(len_mean >= 1)) throw Error(JK_ERR_ARG, "len_mean must be >= 1");
+        if (!(len_sd >= 0)) throw Error(JK_ERR_ARG, "len_sd must be >= 0");
+        if (n_threads == 0) throw Error(JK_ERR_ARG, "n_threads must be >= 1");
+        double psum = 0;
+        for (int i = 0; i < 4; i++) { if (!(pi_tcag[i] >= 0)) throw Error(JK_ERR_ARG, "pi_tcag must be >= 0"); psum += pi_tcag[i]; }
+        if (!(psum > 0)) throw Error(JK_ERR_ARG, "at least one of pi_tcag must be > 0");
+        const double shape = (len_mean * len_mean) / (len_sd * len_sd), scale = (len_sd * len_sd) / len_mean;
+        if (len_sd > 0 && shape < 1.0) throw Error(JK_ERR_UNSUPPORTED, "len_sd > len_mean (gamma shape < 1) is not implemented on the GPU path");
+        JK_HIP(hipSetDevice(device));
+        std::unique_ptr<jk_genome> G(new jk_genome);
+        G->device = device;
+
+        // ---- host: seeds, lengths, first state of every chromosome
+        SeedReader sr{*seeds};
+        const uint64_t T = n_threads;
+        std::vector<uint32_t> lane_seed(T * 8);
+        for (uint64_t t = 0; t < T; t++) sr.take8(&lane_seed[t * 8]);           // mt_seeds (src/pcg.h:63-71)
+        G->seed_words_used = sr.pos;
+        jk_gamma_param gp;
+        gp.a1 = shape - 1.0 / 3.0; gp.a2 = 1.0 / std::sqrt(9.0 * gp.a1); gp.beta = scale;
+        std::vector<uint64_t> len(n_chroms), start(2 * n_chroms), inc(2 * T), adv(T * 64 * 4);
+        std::vector<uint32_t> lane_of(n_chroms);
+        // omp for schedule(static): contiguous blocks, the first n_chroms % T threads get one more
+        const std::vector<uint64_t> per_lane = split_int(n_chroms, T);
+        uint64_t c = 0;
+        for (uint64_t t = 0; t < T; t++) {
+            HostPcg eng{jk_pcg_seed(&lane_seed[t * 8])};
+            PcgMap map[64];
+            pcg_advance_table(eng.e, map);
+            inc[2 * t] = eng.e.inc_hi; inc[2 * t + 1] = eng.e.inc_lo;
+            for (int k = 0; k < 64; k++) {
+                uint64_t* a = &adv[(t * 64 + k) * 4];
+                a[0] = (uint64_t)(map[k].mult >> 64); a[1] = (uint64_t)map[k].mult;
+                a[2] = (uint64_t)(map[k].plus >> 64); a[3] = (uint64_t)map[k].plus;
+            }
+            jk_gamma_state gs{0.0, 0};
+            for (uint64_t i = 0; i < per_lane[t]; i++, c++) {
+                uint64_t L;
+                if (len_sd > 0) {
+                    const double g = jk_gamma(gp, gs, eng);
+                    L = g >= 18446744073709551616.0 ? ~0ULL : (uint64_t)g;
+                    if (L < 1) L = 1;
+                } else L = (uint64_t)len_mean;
+                if (L >= (1ULL << 62)) throw Error(JK_ERR_UNSUPPORTED, "chromosome length >= 2^62");
+                len[c] = L;
+                lane_of[c] = (uint32_t)t;
+                start[2 * c] = eng.e.s_hi; start[2 * c + 1] = eng.e.s_lo;
+                pcg_advance(eng.e, map, 2 * L);                   // AliasSampler::sample takes two outputs per base
+            }
+        }
+        // ---- layout + device tables
+        G->off.resize(n_chroms); G->len = len;
+        std::vector<uint64_t> run_first(n_chroms + 1, 0);
+        uint64_t total = 0;
+        for (uint64_t i = 0; i < n_chroms; i++) {
+            G->off[i] = total;
+            total = align_up(total + len[i], 64);
+            run_first[i + 1] = run_first[i] + (len[i] + GENOME_RUN - 1) / GENOME_RUN;
+            G->names.push_back("chrom" + std::to_string(i));      // create_genome_cpp, src/create_sequences.cpp:163-166
+        }
+        G->seq.alloc(total);
+        const AliasTable at = alias_build(std::vector<double>(pi_tcag, pi_tcag + 4));
+        GenomeKernelParams P{};
+        for (int i = 0; i < 4; i++) {
+            const Threshold th = threshold_lt(at.prob[i]);
+            P.thresh[i] = th.all ? ~0ULL : th.th;
+            P.alias[i] = th.all ? (uint32_t)i : (uint32_t)at.alias[i];
+        }
+        DevBuf d_off, d_len, d_first, d_start, d_lane, d_inc, d_adv;
+        d_off.upload(G->off); d_len.upload(len); d_first.upload(run_first); d_start.upload(start);
+        d_lane.upload(lane_of); d_inc.upload(inc); d_adv.upload(adv);
+        P.out = G->seq.as<uint8_t>();
+        P.chrom_off = d_off.as<uint64_t>(); P.chrom_len = d_len.as<uint64_t>(); P.run_first = d_first.as<uint64_t>();
+        P.start_state = d_start.as<uint64_t>(); P.chrom_lane = d_lane.as<uint32_t>();
+        P.lane_inc = d_inc.as<uint64_t>(); P.lane_adv = d_adv.as<uint64_t>();
+        P.n_runs = run_first[n_chroms]; P.n_chroms = (uint32_t)n_chroms;
+        const uint64_t grid = (P.n_runs + GENOME_BLOCK - 1) / GENOME_BLOCK;
+        if (grid > 0x7fffffffULL) throw Error(JK_ERR_UNSUPPORTED, "genome too large for one launch");
+        hipEvent_t e0, e1;
+        JK_HIP(hipEventCreate(&e0)); JK_HIP(hipEventCreate(&e1));
+        JK_HIP(hipEventRecord(e0, nullptr));
+        hipLaunchKernelGGL(create_genome_kernel, dim3((uint32_t)grid), dim3(GENOME_BLOCK), 0, nullptr, P);
+        JK_HIP(hipGetLastError());
+        JK_HIP(hipEventRecord(e1, nullptr));
+        JK_HIP(hipDeviceSynchronize());
+        float t = 0;
+        JK_HIP(hipEventElapsedTime(&t, e0, e1));
+        G->ms = t;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *out = G.release();
+    });
+}
+
+int jk_genome_view(jk_genome* g, jk_ref_genome* view) {
+    return guarded([&] {
+        if (!g || !view) throw Error(JK_ERR_ARG, "NULL pointer");
+        g->v_names.clear(); g->v_seqs.clear();
+        for (size_t i = 0; i < g->names.size(); i++) {
+            g->v_names.push_back(g->names[i].c_str());
+            g->v_seqs.push_back(g->seq.as<char>() + g->off[i]);
+        }
+        view->n_chroms = g->names.size();
+        view->chrom_names = g->v_names.data();
+        view->chrom_seqs = g->v_seqs.data();
+        view->chrom_lens = g->len.data();
+        view->name = "REF";
+        view->seqs_on_device = 1;
+    });
+}
+
+int jk_genome_fetch(const jk_genome* g, uint64_t chrom, char* dst, uint64_t cap) {
+    return guarded([&] {
+        if (!g || !dst) throw Error(JK_ERR_ARG, "NULL pointer");
+        if (chrom >= g->len.size()) throw Error(JK_ERR_ARG, "chromosome index out of range");
+        if (cap < g->len[chrom]) throw Error(JK_ERR_ARG, "destination too small");
+        JK_HIP(hipSetDevice(g->device));
+        JK_HIP(hipMemcpy(dst, g->seq.as<uint8_t>() + g->off[chrom], g->len[chrom], hipMemcpyDeviceToHost));
+    });
+}
+
+uint64_t jk_genome_seed_words_used(const jk_genome* g) { return g ? g->seed_words_used : 0; }
+double jk_genome_ms(const jk_genome* g) { return g ? g->ms : 0.0; }
+void jk_genome_free(jk_genome* g) { delete g; }
+
+// the jump-ahead create_genome relies on, on its own (host): seed, jump `steps` outputs ahead, n outputs
+void jk_pcg_advance_outputs(const uint32_t* words8, uint64_t steps, uint64_t n, uint64_t* out) {
+    jk_pcg64 e = jk_pcg_seed(words8);
+    PcgMap map[64];
+    pcg_advance_table(e, map);
+    pcg_advance(e, map, steps);
+    for (uint64_t i = 0; i < n; i++) out[i] = jk_pcg_next(e);
+}
 
 uint64_t jk_bgzf_bound(uint64_t n) { return bgzf_bound(n); }
 

@@ -55,6 +55,25 @@ struct HostPcg {
     uint64_t operator()() { return jk_pcg_next(e); }
 };
 
+// LCG jump-ahead (engine::advance, pcg_random.hpp:419-429) as a table: map[k] carries a state 2^k steps
+// forward, state -> mult * state + plus.  Stepping an arbitrary distance applies the maps of its set
+// bits (they are powers of one map, so the order does not matter).
+struct PcgMap { jk_u128 mult, plus; };
+inline void pcg_advance_table(const jk_pcg64& e, PcgMap map[64]) {
+    jk_u128 m = jk_mk128(JK_PCG_MULT_HI, JK_PCG_MULT_LO), c = jk_mk128(e.inc_hi, e.inc_lo);
+    for (int k = 0; k < 64; k++) {
+        map[k].mult = m; map[k].plus = c;
+        c = (m + 1) * c;
+        m = m * m;
+    }
+}
+inline void pcg_advance(jk_pcg64& e, const PcgMap map[64], uint64_t steps) {
+    jk_u128 st = jk_mk128(e.s_hi, e.s_lo);
+    for (int k = 0; steps; k++, steps >>= 1)
+        if (steps & 1u) st = map[k].mult * st + map[k].plus;
+    e.s_hi = (uint64_t)(st >> 64); e.s_lo = (uint64_t)st;
+}
+
 inline std::vector<uint64_t> split_int(uint64_t x, uint64_t n) {
     std::vector<uint64_t> out(n, x / n);
     uint64_t extra = x - n * (x / n);          // the first `extra` chunks get one more

@@ -36,8 +36,94 @@ class RefGenome:
         names = (C.c_char_p * n)(*[x.encode() for x in self.names])
         ptrs = (C.c_void_p * n)(*[s.ctypes.data for s in self.seqs])
         lens = (C.c_uint64 * n)(*[s.size for s in self.seqs])
-        v = _abi.RefGenomeView(n, names, ptrs, lens, self.name.encode())
+        v = _abi.RefGenomeView(n, names, ptrs, lens, self.name.encode(), 0)
         return v, [names, ptrs, lens, self.seqs]
+
+
+class DeviceGenome(RefGenome):
+    """A reference genome that was made on the GPU and lives there (``jk_genome``); what ``create_genome``
+    returns.  illumina()/pacbio() read it in place; ``seqs`` (host copies) are fetched on first use."""
+
+    def __init__(self, handle, n_chroms):
+        self._h = handle
+        L = _abi.lib()
+        v = _abi.RefGenomeView()
+        _abi.check(L.jk_genome_view(self._h, C.byref(v)))
+        self.names = [v.chrom_names[i].decode() for i in range(n_chroms)]
+        self._sizes = [int(v.chrom_lens[i]) for i in range(n_chroms)]
+        self.name = "REF"
+        self._seqs = None
+
+    def n_chroms(self):
+        return len(self._sizes)
+
+    def sizes(self):
+        return list(self._sizes)
+
+    def seed_words_used(self):
+        return int(_abi.lib().jk_genome_seed_words_used(self._h))
+
+    def kernel_ms(self):
+        return float(_abi.lib().jk_genome_ms(self._h))
+
+    def chrom(self, i):
+        out = np.empty(max(self._sizes[i], 1), dtype=np.uint8)
+        _abi.check(_abi.lib().jk_genome_fetch(self._h, i, out.ctypes.data, out.size))
+        return out[:self._sizes[i]]
+
+    @property
+    def seqs(self):
+        if self._seqs is None:
+            self._seqs = [self.chrom(i) for i in range(self.n_chroms())]
+        return self._seqs
+
+    def _view(self):
+        v = _abi.RefGenomeView()
+        _abi.check(_abi.lib().jk_genome_view(self._h, C.byref(v)))
+        return v, [self]
+
+    def close(self):
+        if self._h:
+            _abi.lib().jk_genome_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def create_genome(n_chroms, len_mean, len_sd=0, pi_tcag=(0.25, 0.25, 0.25, 0.25), n_threads=1, seed_words=None,
+                  seed=None, device=0):
+    """create_genome() of the reference (/root/reference/R/create_genome.R:26-56 -> create_genome_cpp,
+    /root/reference/src/create_sequences.cpp:151-169), made on the GPU.  ``seed_words``: 8 32-bit words per
+    thread (what the reference draws from R's RNG); or ``seed`` for this package's SplitMix64 stream."""
+    from .rng import seed_words as _sw
+
+    def err(par, what):
+        raise ValueError("\nFor the `create_genome` function in jackalope, argument `%s` must be %s." % (par, what))
+    if not isinstance(n_chroms, (int, np.integer)) or isinstance(n_chroms, bool) or n_chroms < 1:
+        err("n_chroms", "a single integer >= 1")
+    if not isinstance(len_mean, (int, float, np.integer, np.floating)) or isinstance(len_mean, bool) or not len_mean >= 1:
+        err("len_mean", "a single number >= 1")
+    if not isinstance(len_sd, (int, float, np.integer, np.floating)) or isinstance(len_sd, bool) or not len_sd >= 0:
+        err("len_sd", "a single number >= 0")
+    pi = np.asarray(pi_tcag, dtype=np.float64)
+    if pi.shape != (4,) or np.any(~(pi >= 0)) or np.all(pi == 0):
+        err("pi_tcag", "a numeric vector of length 4, where no number can be < 0 and at least one must be > 0")
+    if not isinstance(n_threads, (int, np.integer)) or isinstance(n_threads, bool) or n_threads < 1:
+        err("n_threads", "a single integer >= 1")
+    if seed_words is None:
+        seed_words = _sw(0 if seed is None else seed, 8 * int(n_threads))
+    words = np.ascontiguousarray(seed_words, dtype=np.uint32)
+    src = _abi.SeedSource()
+    src.words = words.ctypes.data_as(C.POINTER(C.c_uint32))
+    src.n_words = words.size
+    h = C.c_void_p()
+    _abi.check(_abi.lib().jk_create_genome(int(n_chroms), float(len_mean), float(len_sd), pi.ctypes.data_as(C.POINTER(C.c_double)),
+                                           int(n_threads), C.byref(src), int(device), C.byref(h)))
+    return DeviceGenome(h, int(n_chroms))
 
 
 def synthetic_genome(chrom_sizes, seed, alphabet=b"TCAG"):

@@ -1548,4 +1548,50 @@ int orc_pacbio_hap(const orc_hap_set* hs, const double* hap_probs, const orc_pac
 double orc_pnorm(double x) { return pnorm_std(x); }
 double orc_qchisq(double p, double df) { return qchisq_upper_tail_point(p, df); }
 
+// create_chromosomes_ / create_genome_cpp (src/create_sequences.cpp:59-169): mt_seeds for n_threads engines,
+// chromosomes dealt to threads by `omp for schedule(static)` (GCC/LLVM: contiguous blocks, the first
+// n_chroms % n_threads threads get one more), per chromosome one gamma length draw (when len_sd > 0) and
+// one alias draw per base over pi_tcag.  Run here thread after thread; the result does not depend on
+// how the threads interleave.  lens[n_chroms]; *blob = concatenated chromosomes (orc_free).
+int orc_create_genome(uint64_t n_chroms, double len_mean, double len_sd, const double* pi_tcag, uint64_t n_threads,
+                      const uint32_t* seed_words, uint64_t n_seed_words, uint64_t* lens, char** blob,
+                      uint64_t* blob_len, uint64_t* seed_words_used) {
+    try {
+        SeedSource seeds{seed_words, n_seed_words, 0};
+        std::vector<const uint32_t*> tseeds(n_threads);
+        for (u64 t = 0; t < n_threads; t++) tseeds[t] = seeds.take8();
+        const Alias sampler(std::vector<double>(pi_tcag, pi_tcag + 4));
+        const double gamma_shape = (len_mean * len_mean) / (len_sd * len_sd);
+        const double gamma_scale = (len_sd * len_sd) / len_mean;
+        const std::string bases = "TCAG";
+        std::vector<std::string> chroms(n_chroms);
+        const u64 q = n_chroms / n_threads, r = n_chroms % n_threads;
+        for (u64 t = 0; t < n_threads; t++) {
+            const u64 i0 = t < r ? (q + 1) * t : q * t + r;
+            const u64 i1 = i0 + (t < r ? q + 1 : q);
+            Pcg64 engine = seeded_pcg(tseeds[t]);
+            std::gamma_distribution<double> distr;
+            if (len_sd > 0) distr = std::gamma_distribution<double>(gamma_shape, gamma_scale);
+            for (u64 i = i0; i < i1; i++) {
+                u64 len;
+                if (len_sd > 0) {
+                    len = static_cast<u64>(distr(engine));
+                    if (len < 1) len = 1;
+                } else len = static_cast<u64>(len_mean);
+                std::string& chrom = chroms[i];
+                chrom.reserve(len);
+                for (u64 j = 0; j < len; j++) chrom.push_back(bases[sampler.sample(engine)]);
+            }
+        }
+        u64 total = 0;
+        for (u64 i = 0; i < n_chroms; i++) { lens[i] = chroms[i].size(); total += lens[i]; }
+        char* out = static_cast<char*>(std::malloc(total ? total : 1));
+        if (!out) throw std::runtime_error("oracle: out of memory");
+        u64 at = 0;
+        for (u64 i = 0; i < n_chroms; i++) { std::memcpy(out + at, chroms[i].data(), lens[i]); at += lens[i]; }
+        *blob = out; *blob_len = total; *seed_words_used = seeds.pos;
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
 }  // extern "C"

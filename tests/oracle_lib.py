@@ -306,3 +306,22 @@ def pacbio_hap(hs, pb, *, hap_probs, n_reads, n_threads, words, **kw):
     if rc != 0:
         raise RuntimeError(lib().orc_last_error().decode())
     return _take(o, ln.value), used.value, tb
+
+
+def create_genome(n_chroms, len_mean, len_sd, pi_tcag, n_threads, words):
+    """Oracle run of create_genome_cpp; returns (list of chromosome bytes, seed words used)."""
+    pi = np.asarray(pi_tcag, dtype=np.float64)
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    lens = np.zeros(int(n_chroms), dtype=np.uint64)
+    blob, blen, used = C.c_void_p(), C.c_uint64(), C.c_uint64()
+    rc = lib().orc_create_genome(C.c_uint64(int(n_chroms)), C.c_double(len_mean), C.c_double(len_sd), pi.ctypes.data_as(C.c_void_p),
+                                 C.c_uint64(int(n_threads)), w.ctypes.data_as(C.c_void_p), C.c_uint64(w.size),
+                                 lens.ctypes.data_as(C.c_void_p), C.byref(blob), C.byref(blen), C.byref(used))
+    if rc != 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+    raw = _take(blob, blen.value)
+    out, at = [], 0
+    for n in lens.tolist():
+        out.append(raw[at:at + n])
+        at += n
+    return out, used.value
