@@ -223,6 +223,16 @@ int jk_create_genome(uint64_t n_chroms, double len_mean, double len_sd, const do
                      jk_seed_source* seeds, int device, jk_genome** out);
 int jk_genome_view(jk_genome* g, jk_ref_genome* view);
 int jk_genome_fetch(const jk_genome* g, uint64_t chrom, char* dst, uint64_t cap);
+/* read_fasta (fourth "next" row): read_fasta_noind / read_fasta_ind
+ * (src/io_fasta.cpp:153-169, :389-408; R/read_write.R:24-52).  Files may be plain, gzip or bgzip (zlib's
+ * gzread, as in the reference).  fai_files NULL = non-indexed: a line containing '>' starts a
+ * chromosome (cut_names: name up to the first space), sequence lines lose '\n' and one '\r' before
+ * it; with index files the spans they list are read and only '\n' is dropped.  Every sequence byte
+ * goes through the reference's filter (TCAGN kept, tcagn upper-cased when remove_soft_mask, anything
+ * else becomes a zero byte).  The host reads the file and locates header lines; newline removal,
+ * filtering and packing run on the device, where the genome stays (same handle as jk_create_genome). */
+int jk_read_fasta(const char* const* fasta_files, const char* const* fai_files, uint64_t n_files, int32_t cut_names,
+                  int32_t remove_soft_mask, int device, jk_genome** out);
 uint64_t jk_genome_seed_words_used(const jk_genome* g);
 double jk_genome_ms(const jk_genome* g);          /* device milliseconds of the generating kernel */
 void jk_genome_free(jk_genome* g);

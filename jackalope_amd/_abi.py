@@ -112,7 +112,7 @@ EXPORTS = [
     "jk_hap_builder_new", "jk_hap_builder_from", "jk_add_substitution", "jk_add_insertion", "jk_add_deletion",
     "jk_hap_builder_view", "jk_hap_builder_free",
     "jk_bgzf_bound", "jk_bgzf_deflate",
-    "jk_pcg_advance_outputs", "jk_create_genome", "jk_genome_view", "jk_genome_fetch", "jk_genome_seed_words_used", "jk_genome_ms", "jk_genome_free",
+    "jk_pcg_advance_outputs", "jk_create_genome", "jk_read_fasta", "jk_genome_view", "jk_genome_fetch", "jk_genome_seed_words_used", "jk_genome_ms", "jk_genome_free",
 ]
 
 _lib = None
@@ -175,6 +175,8 @@ def lib():
                                    C.POINTER(SeedSource), C.c_int, C.POINTER(C.c_void_p)]
     L.jk_pcg_advance_outputs.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     L.jk_pcg_advance_outputs.restype = None
+    L.jk_read_fasta.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint64, C.c_int32, C.c_int32, C.c_int,
+                                C.POINTER(C.c_void_p)]
     L.jk_genome_view.argtypes = [C.c_void_p, C.POINTER(RefGenomeView)]
     L.jk_genome_fetch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
     L.jk_genome_seed_words_used.restype = C.c_uint64

@@ -44,12 +44,13 @@ class DeviceGenome(RefGenome):
     """A reference genome that was made on the GPU and lives there (``jk_genome``); what ``create_genome``
     returns.  illumina()/pacbio() read it in place; ``seqs`` (host copies) are fetched on first use."""
 
-    def __init__(self, handle, n_chroms):
+    def __init__(self, handle, n_chroms=None):
         self._h = handle
         L = _abi.lib()
         v = _abi.RefGenomeView()
         _abi.check(L.jk_genome_view(self._h, C.byref(v)))
-        self.names = [v.chrom_names[i].decode() for i in range(n_chroms)]
+        n_chroms = int(v.n_chroms) if n_chroms is None else n_chroms
+        self.names = [v.chrom_names[i].decode(errors="replace") for i in range(n_chroms)]
         self._sizes = [int(v.chrom_lens[i]) for i in range(n_chroms)]
         self.name = "REF"
         self._seqs = None
@@ -124,6 +125,32 @@ def create_genome(n_chroms, len_mean, len_sd=0, pi_tcag=(0.25, 0.25, 0.25, 0.25)
     _abi.check(_abi.lib().jk_create_genome(int(n_chroms), float(len_mean), float(len_sd), pi.ctypes.data_as(C.POINTER(C.c_double)),
                                            int(n_threads), C.byref(src), int(device), C.byref(h)))
     return DeviceGenome(h, int(n_chroms))
+
+
+def read_fasta(fasta_files, fai_files=None, cut_names=False, device=0):
+    """read_fasta() of the reference (/root/reference/R/read_write.R:24-52 -> read_fasta_noind /
+    read_fasta_ind, /root/reference/src/io_fasta.cpp:153-169, :389-408): plain, gzip or bgzip FASTA
+    file(s), optionally with index files, into a genome that is packed on and stays on the GPU.
+    Soft masking is always removed, as the R function does."""
+    def err(par, *what):
+        raise ValueError("\nFor the `read_fasta` function in jackalope, argument `%s` must be %s." % (par, " ".join(what)))
+    if isinstance(fasta_files, str):
+        fasta_files = [fasta_files]
+    if not isinstance(fasta_files, (list, tuple)) or len(fasta_files) == 0 or not all(isinstance(f, str) for f in fasta_files):
+        err("fasta_files", "a character vector")
+    if isinstance(fai_files, str):
+        fai_files = [fai_files]
+    if fai_files is not None and (not isinstance(fai_files, (list, tuple)) or len(fai_files) != len(fasta_files)
+                                  or not all(isinstance(f, str) for f in fai_files)):
+        err("fai_files", "NULL or a character vector of the same", "length as the `fasta_files` argument")
+    if not isinstance(cut_names, (bool, np.bool_)):
+        err("cut_names", "a single logical")
+    n = len(fasta_files)
+    fa = (C.c_char_p * n)(*[f.encode() for f in fasta_files])
+    fai = (C.c_char_p * n)(*[f.encode() for f in fai_files]) if fai_files is not None else None
+    h = C.c_void_p()
+    _abi.check(_abi.lib().jk_read_fasta(fa, fai, n, int(bool(cut_names)), 1, int(device), C.byref(h)))
+    return DeviceGenome(h)
 
 
 def synthetic_genome(chrom_sizes, seed, alphabet=b"TCAG"):

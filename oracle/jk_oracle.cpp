@@ -31,6 +31,8 @@
 #include <random>
 #include <string>
 #include <vector>
+#include <zlib.h>
+#include <cerrno>
 #include <stdexcept>
 #include <algorithm>
 #include <numeric>
@@ -1590,6 +1592,149 @@ int orc_create_genome(uint64_t n_chroms, double len_mean, double len_sd, const d
         u64 at = 0;
         for (u64 i = 0; i < n_chroms; i++) { std::memcpy(out + at, chroms[i].data(), lens[i]); at += lens[i]; }
         *blob = out; *blob_len = total; *seed_words_used = seeds.pos;
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// ---- FASTA reader (src/io_fasta.cpp:41-169 non-indexed, :183-408 indexed) restated with the reference's own
+// buffering: 4095-byte gzread pieces turned into C strings (so a NUL byte in the file truncates the piece),
+// lines split on '\n' with one trailing '\r' dropped, a line containing '>' anywhere starts a chromosome,
+// every sequence byte mapped through the filter tables of src/str_manip.h:24-56 (anything but
+// TCAGN/tcagn becomes a zero byte).
+}  // extern "C" (helpers below are C++)
+
+namespace {
+
+struct FaChrom { std::string name, nucleos; };
+
+char fa_filter(char c, bool upper) {
+    switch (c) {
+        case 'T': case 'C': case 'A': case 'G': case 'N': return c;
+        case 't': case 'c': case 'a': case 'g': case 'n': return upper ? static_cast<char>(c - 32) : c;
+        default: return 0;
+    }
+}
+
+std::vector<std::string> split_newline(const std::string& in) {          // cpp_str_split_newline, src/str_manip.h:142-171
+    std::vector<std::string> out(1, "");
+    std::string::size_type i0 = 0, i = in.find('\n');
+    while (i != std::string::npos) {
+        out.back().append(in, i0, i - i0);
+        if (!out.back().empty() && out.back().back() == '\r') out.back().pop_back();
+        i0 = i + 1;
+        i = in.find('\n', i0);
+        out.push_back("");
+    }
+    out.back().append(in, i0, std::string::npos);
+    return out;
+}
+
+void fa_parse_line(const std::string& line, bool cut_names, std::vector<FaChrom>& ref) {   // parse_fasta_line, :43-65
+    if (line.find(">") != std::string::npos) {
+        std::string name;
+        if (cut_names) {
+            std::string::size_type spc = line.find(' ', 2);
+            if (spc == std::string::npos) spc = line.size();
+            name = line.substr(1, spc);
+            name.erase(std::remove_if(name.begin(), name.end(), ::isspace), name.end());
+        } else name = line.substr(1, line.size());
+        ref.push_back(FaChrom{name, ""});
+    } else {
+        if (ref.empty()) throw std::runtime_error("oracle: sequence line before the first '>' line");
+        ref.back().nucleos += line;
+    }
+}
+
+void fa_append_noind(std::vector<FaChrom>& ref, const std::string& fn, bool cut_names, bool upper) {   // append_ref_noind, :74-136
+    gzFile file = gzopen(fn.c_str(), "rb");
+    if (!file) throw std::runtime_error("gzopen of " + fn + " failed: " + strerror(errno) + ".\n");
+    const size_t first_new = ref.size();
+    std::string lastline;
+    std::vector<char> buffer(0x1000);
+    for (;;) {
+        const int bytes_read = gzread(file, buffer.data(), 0x1000 - 1);
+        if (bytes_read < 0) { gzclose(file); throw std::runtime_error("gzread failed"); }
+        buffer[bytes_read] = '\0';
+        std::string mystring = lastline + std::string(buffer.data());
+        std::vector<std::string> svec = split_newline(mystring);
+        for (size_t i = 0; i + 1 < svec.size(); i++) fa_parse_line(svec[i], cut_names, ref);
+        lastline = svec.back();
+        if (bytes_read < 0x1000 - 1) {
+            if (gzeof(file)) { fa_parse_line(lastline, cut_names, ref); break; }
+        }
+    }
+    gzclose(file);
+    (void)first_new;
+    for (FaChrom& c : ref) for (char& ch : c.nucleos) ch = fa_filter(ch, upper);     // all chromosomes, again (:130-133)
+}
+
+void fa_append_ind(std::vector<FaChrom>& ref, const std::string& fn, const std::string& fai, bool upper) {   // :270-370
+    std::vector<u64> offsets, lengths, line_lens;
+    std::vector<std::string> names;
+    {
+        gzFile f = gzopen(fai.c_str(), "rb");
+        if (!f) throw std::runtime_error("gzopen of " + fai + " failed: " + strerror(errno) + ".\n");
+        std::string all; char buf[4096]; int n;
+        while ((n = gzread(f, buf, sizeof buf)) > 0) all.append(buf, n);
+        gzclose(f);
+        for (const std::string& line : split_newline(all)) {
+            if (line.empty()) continue;
+            std::vector<std::string> cols(1, "");
+            for (char ch : line) { if (ch == '\t') cols.push_back(""); else cols.back() += ch; }
+            if (cols.size() < 4) throw std::runtime_error("oracle: short fai line");
+            names.push_back(cols[0]); lengths.push_back(std::stoull(cols[1]));
+            offsets.push_back(std::stoull(cols[2])); line_lens.push_back(std::stoul(cols[3]));
+        }
+    }
+    gzFile file = gzopen(fn.c_str(), "rb");
+    if (!file) throw std::runtime_error("gzopen of " + fn + " failed: " + strerror(errno) + ".\n");
+    const u64 LIMIT = 4194304;
+    for (size_t i = 0; i < offsets.size(); i++) {
+        FaChrom rs; rs.name = names[i];
+        const u64 len = lengths[i] + lengths[i] / line_lens[i] + 1;
+        for (u64 j = 0; j < len; j += (LIMIT - 1)) {
+            gzseek(file, offsets[i] + j, SEEK_SET);
+            u64 partial_len = LIMIT;
+            if (len - j < LIMIT) partial_len = len - j;
+            std::vector<char> buffer(partial_len);
+            const long bytes_read = gzread(file, buffer.data(), partial_len - 1);
+            buffer[bytes_read > 0 ? bytes_read : 0] = '\0';
+            std::string chrom_str(buffer.data());
+            chrom_str.erase(std::remove(chrom_str.begin(), chrom_str.end(), '\n'), chrom_str.end());
+            for (char& ch : chrom_str) ch = fa_filter(ch, upper);
+            rs.nucleos += chrom_str;
+            if (bytes_read < static_cast<long>(partial_len) && gzeof(file)) break;      // "fai file lengths appear incorrect"
+        }
+        ref.push_back(rs);
+    }
+    gzclose(file);
+}
+
+}  // namespace
+
+extern "C" {
+
+// read_fasta_noind / read_fasta_ind.  fai_files may be NULL.  Returns names joined by '\n', lens[], and the
+// concatenated sequences (all malloc'd; orc_free).
+int orc_read_fasta(const char* const* fasta_files, const char* const* fai_files, uint64_t n_files, int cut_names,
+                   int remove_soft_mask, uint64_t* n_chroms, char** names, uint64_t* names_len, uint64_t** lens,
+                   char** seqs, uint64_t* seqs_len) {
+    try {
+        std::vector<FaChrom> ref;
+        for (uint64_t i = 0; i < n_files; i++) {
+            if (fai_files) fa_append_ind(ref, fasta_files[i], fai_files[i], remove_soft_mask != 0);
+            else fa_append_noind(ref, fasta_files[i], cut_names != 0, remove_soft_mask != 0);
+        }
+        std::string nm, sq;
+        uint64_t* L = static_cast<uint64_t*>(std::malloc(sizeof(uint64_t) * (ref.size() + 1)));
+        for (size_t i = 0; i < ref.size(); i++) {
+            if (i) nm += '\n';
+            nm += ref[i].name; sq += ref[i].nucleos; L[i] = ref[i].nucleos.size();
+        }
+        *n_chroms = ref.size();
+        *names = static_cast<char*>(std::malloc(nm.size() + 1)); std::memcpy(*names, nm.data(), nm.size()); *names_len = nm.size();
+        *seqs = static_cast<char*>(std::malloc(sq.size() + 1)); std::memcpy(*seqs, sq.data(), sq.size()); *seqs_len = sq.size();
+        *lens = L;
         return 0;
     } catch (std::exception& e) { g_err = e.what(); return 1; }
 }

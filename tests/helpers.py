@@ -93,3 +93,25 @@ def builder_haplotypes(ja, sizes, n_haps, n_edits, seed, max_indel=10):
                 else:
                     b.add_del(h, c, pos, min(int(rng.exponential(2.0) + 1.0), max_indel))
     return b.snapshot()
+
+
+def write_fasta(fn, names, chroms, text_width=80, newline=b"\n"):
+    """What write_ref_fasta__ writes (/root/reference/src/io_fasta.cpp:431-480): '>' + name, then lines of text_width."""
+    with open(fn, "wb") as f:
+        for name, c in zip(names, chroms):
+            f.write(b">" + name.encode() + newline)
+            for i in range(0, len(c), text_width):
+                f.write(bytes(c[i:i + text_width]) + newline)
+
+
+def write_fai(fn, names, chroms, text_width=80, newline_len=1):
+    """The index of a file made by write_fasta, as tests/testthat/test-fasta_IO.R:218-235 builds one:
+    name, length, byte offset of the first base, bases per line, bytes per line."""
+    at = 0
+    with open(fn, "w") as f:
+        for name, c in zip(names, chroms):
+            at += len(name) + 1 + newline_len
+            f.write("%s\t%d\t%d\t%d\t%d\n" % (name, len(c), at, text_width, text_width + newline_len))
+            n_lines = (len(c) + text_width - 1) // text_width
+            at += len(c) + n_lines * newline_len
+    return fn

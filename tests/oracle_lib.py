@@ -325,3 +325,24 @@ def create_genome(n_chroms, len_mean, len_sd, pi_tcag, n_threads, words):
         out.append(raw[at:at + n])
         at += n
     return out, used.value
+
+
+def read_fasta(fasta_files, fai_files=None, cut_names=False, remove_soft_mask=True):
+    """Oracle run of read_fasta_noind / read_fasta_ind; returns (names as bytes, chromosome bytes)."""
+    n = len(fasta_files)
+    fa = (C.c_char_p * n)(*[f.encode() for f in fasta_files])
+    fai = (C.c_char_p * n)(*[f.encode() for f in fai_files]) if fai_files is not None else None
+    nc, names, nl, lens, seqs, sl = C.c_uint64(), C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+    rc = lib().orc_read_fasta(fa, fai, C.c_uint64(n), C.c_int(int(cut_names)), C.c_int(int(remove_soft_mask)), C.byref(nc),
+                              C.byref(names), C.byref(nl), C.byref(lens), C.byref(seqs), C.byref(sl))
+    if rc != 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+    L = np.frombuffer(C.string_at(lens, 8 * nc.value), dtype=np.uint64).tolist() if nc.value else []
+    lib().orc_free(lens)
+    nm = _take(names, nl.value)
+    sq = _take(seqs, sl.value)
+    out, at = [], 0
+    for k in L:
+        out.append(sq[at:at + k])
+        at += k
+    return (nm.split(b"\n") if nc.value else []), out
