@@ -248,6 +248,71 @@ def create_genome_main(a):
     print(json.dumps(out))
 
 
+def read_fasta_main(a):
+    """Secondary line: read_fasta() of an uncompressed FASTA (24 chromosomes, 80 columns) made by this run in a
+    temporary directory.  `value` is end to end (host file read + upload + device packing); the roofline is the
+    device packing alone.  --genome-mbp sets the size (default 1000 Mbp)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import torch
+    import jackalope_amd as ja
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    mbp = a.genome_mbp if a.genome_mbp != 100.0 else 1000.0
+    n_chroms = 24
+    chrom_len = int(mbp * 1e6 / n_chroms) // 80 * 80
+    tmp = tempfile.mkdtemp(prefix="jk_bench_fa_")
+    try:
+        fn = os.path.join(tmp, "ref.fa")
+        g0 = ja.create_genome(n_chroms, chrom_len, 0, seed_words=ja.seed_words(5, 8), device=local_rank)
+        with open(fn, "wb") as f:
+            for i in range(n_chroms):
+                f.write(b">chrom%d\n" % i)
+                rows = g0.chrom(i).reshape(-1, 80)
+                f.write(np.concatenate([rows, np.full((rows.shape[0], 1), 10, dtype=np.uint8)], axis=1).tobytes())
+        g0.close()
+        file_bytes = os.path.getsize(fn)
+        bases = n_chroms * chrom_len
+
+        def step():
+            g = ja.read_fasta(fn, device=local_rank)
+            ms = g.kernel_ms()
+            g.close()
+            return ms
+        for _ in range(a.warmup):
+            step()
+        t0 = time.perf_counter()
+        dev_ms = 0.0
+        for _ in range(a.steps):
+            dev_ms += step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kern_s = dev_ms / a.steps / 1e3
+        alg = file_bytes + bases                   # text read once, bases written once
+        out = {"metric": "Gbases/sec of read_fasta (uncompressed, end to end)", "value": round(bases * a.steps / elapsed / 1e9, 3),
+               "unit": "Gbases/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "read_fasta of a %d-byte FASTA (24 chromosomes, 80 columns, page cache)" % file_bytes, "bases": bases},
+               "roofline": {"bound": "hbm", "achieved": round(alg / kern_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(alg / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                            "kernel": "fasta_count_kernel + scan + fasta_pack_kernel", "launches_per_step": 1,
+                            "kernel_ms": round(kern_s * 1e3, 3),
+                            "note": "device part only; the count pass re-reads the text, so HBM traffic is about 2x text + bases"}}
+        if not a.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            t1 = time.perf_counter()
+            O.read_fasta([fn])
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(bases / dt / 1e9, 4), "unit": "Gbases/sec", "cores": 1, "kind": "port",
+                                   "sample": "the same file through the oracle's restatement of read_fasta_noind (single-threaded, "
+                                             "as the reference is) (%.1f s)" % dt}
+        print(json.dumps(out))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,7 +323,7 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=100.0)
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = choose for about 15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["illumina", "pacbio", "bgzf", "create_genome"], default="illumina",
+    ap.add_argument("--workload", choices=["illumina", "pacbio", "bgzf", "create_genome", "read_fasta"], default="illumina",
                     help="illumina = the headline metric (BASELINE configs[1]); pacbio = configs[4]-style secondary line; "
                          "bgzf = the device-side compressed sink on the headline workload's FASTQ")
     a = ap.parse_args()
@@ -268,6 +333,8 @@ def main():
         return bgzf_main(a)
     if a.workload == "create_genome":
         return create_genome_main(a)
+    if a.workload == "read_fasta":
+        return read_fasta_main(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

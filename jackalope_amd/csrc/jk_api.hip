@@ -11,6 +11,10 @@
 #include <functional>
 #include <thread>
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <memory>
 #include <string>
 #include <vector>
@@ -1734,22 +1738,57 @@ int jk_genome_fetch(const jk_genome* g, uint64_t chrom, char* dst, uint64_t cap)
 // ---- read_fasta (src/io_fasta.cpp:41-169, :183-408): host reads + finds header lines, device packs ----
 namespace jk {
 
-static std::vector<uint8_t> slurp_gz(const std::string& fn) {
+// Whole (uncompressed) content of a file the way gzread presents it (src/io_fasta.cpp:83-96): gzip and bgzip
+// members are inflated, anything else is passed through -- those files are mapped instead of copied.
+struct HostText {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    void* map = nullptr; size_t map_len = 0;
+    uint8_t* heap = nullptr;
+    HostText() {}
+    HostText(const HostText&) = delete;
+    HostText& operator=(const HostText&) = delete;
+    ~HostText() { if (map) munmap(map, map_len); std::free(heap); }
+    const uint8_t* data() const { return p; }
+    size_t size() const { return n; }
+};
+
+static void slurp_gz(const std::string& fn, HostText& T) {
+    {
+        const int fd = ::open(fn.c_str(), O_RDONLY);
+        if (fd < 0) throw Error(JK_ERR_IO, "gzopen of " + fn + " failed: " + strerror(errno) + ".\n");
+        uint8_t magic[2] = {0, 0};
+        const ssize_t got = ::pread(fd, magic, 2, 0);
+        struct stat st;
+        const bool plain = !(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
+        if (plain && ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+            if (st.st_size > 0) {
+                void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    ::close(fd);
+                    T.map = m; T.map_len = (size_t)st.st_size; T.p = static_cast<const uint8_t*>(m); T.n = T.map_len;
+                    return;
+                }
+            } else { ::close(fd); return; }
+        }
+        ::close(fd);
+    }
     gzFile f = gzopen(fn.c_str(), "rb");
     if (!f) throw Error(JK_ERR_IO, "gzopen of " + fn + " failed: " + strerror(errno) + ".\n");
     gzbuffer(f, 1 << 20);
-    std::vector<uint8_t> data;
-    size_t cap = 1 << 24;
+    size_t cap = 1 << 24, n = 0;
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(cap));
     for (;;) {
-        data.resize(data.size() + cap);
-        const int got = gzread(f, data.data() + data.size() - cap, (unsigned)cap);
-        if (got < 0) { int e; std::string m = gzerror(f, &e); gzclose(f); throw Error(JK_ERR_IO, "Error: " + m + ".\n"); }
-        data.resize(data.size() - cap + (size_t)got);
-        if ((size_t)got < cap) break;
-        if (cap < (1u << 30)) cap <<= 1;
+        if (!buf) { gzclose(f); throw Error(JK_ERR_IO, "out of host memory reading " + fn); }
+        const size_t want = std::min<size_t>(cap - n, 1u << 30);
+        const int got = gzread(f, buf + n, (unsigned)want);
+        if (got < 0) { int e; std::string m = gzerror(f, &e); gzclose(f); std::free(buf); throw Error(JK_ERR_IO, "Error: " + m + ".\n"); }
+        n += (size_t)got;
+        if ((size_t)got < want) break;
+        if (n == cap) { cap += cap / 2; buf = static_cast<uint8_t*>(std::realloc(buf, cap)); }
     }
     gzclose(f);
-    return data;
+    T.heap = buf; T.p = buf; T.n = n;
 }
 
 struct FastaPlan {
@@ -1758,7 +1797,7 @@ struct FastaPlan {
 };
 
 // header lines of a non-indexed file (parse_fasta_line, src/io_fasta.cpp:43-65)
-static FastaPlan plan_noind(const std::vector<uint8_t>& text, bool cut_names) {
+static FastaPlan plan_noind(const HostText& text, bool cut_names) {
     FastaPlan P;
     const uint8_t* t = text.data();
     const uint64_t n = text.size();
@@ -1804,7 +1843,8 @@ static FastaPlan plan_noind(const std::vector<uint8_t>& text, bool cut_names) {
 // spans an index file describes (parse_line_fai / append_ref_ind, src/io_fasta.cpp:183-200, :270-370)
 static FastaPlan plan_ind(const std::string& fai, uint64_t n) {
     FastaPlan P;
-    const std::vector<uint8_t> idx = slurp_gz(fai);
+    HostText idx;
+    slurp_gz(fai, idx);
     size_t at = 0;
     while (at <= idx.size()) {
         const uint8_t* e = at < idx.size() ? static_cast<const uint8_t*>(std::memchr(idx.data() + at, '\n', idx.size() - at)) : nullptr;
@@ -1829,10 +1869,10 @@ static FastaPlan plan_ind(const std::string& fai, uint64_t n) {
 }
 
 // pack one file's text; appends its chromosomes to G
-static void fasta_pack_file(jk_genome& G, const std::vector<uint8_t>& text, const FastaPlan& plan, bool strip_cr, bool upper, double* ms) {
+static void fasta_pack_file(jk_genome& G, const HostText& text, const FastaPlan& plan, bool strip_cr, bool upper, double* ms) {
     const uint64_t n = text.size(), nc = plan.names.size();
     if (nc == 0) return;
-    if (std::memchr(text.data(), 0, n)) throw Error(JK_ERR_UNSUPPORTED, "FASTA file contains NUL bytes (the reference truncates its read buffer there)");
+    if (n && std::memchr(text.data(), 0, n)) throw Error(JK_ERR_UNSUPPORTED, "FASTA file contains NUL bytes (the reference truncates its read buffer there)");
     // intervals sorted by position (index files need not list chromosomes in file order)
     std::vector<uint32_t> order(nc);
     for (uint32_t i = 0; i < nc; i++) order[i] = i;
@@ -1846,7 +1886,7 @@ static void fasta_pack_file(jk_genome& G, const std::vector<uint8_t>& text, cons
     DevBuf d_text, d_ib, d_ie, d_cnt, d_off, d_sums, d_base, d_ivout;
     d_text.alloc(align_up(n, 16) + 64);
     JK_HIP(hipMemset(d_text.as<uint8_t>() + (n & ~15ULL), 0, d_text.n - (n & ~15ULL)));
-    JK_HIP(hipMemcpy(d_text.p, text.data(), n, hipMemcpyHostToDevice));
+    if (n) JK_HIP(hipMemcpy(d_text.p, text.data(), n, hipMemcpyHostToDevice));
     d_ib.upload(ib); d_ie.upload(ie);
     const uint64_t n_blocks = (n + FASTA_BLOCK_BYTES - 1) / FASTA_BLOCK_BYTES + 1;     // + 1: a block that owns position n
     if (n_blocks > 0x7fffffffULL) throw Error(JK_ERR_UNSUPPORTED, "FASTA file too large for one launch");
@@ -1909,7 +1949,8 @@ int jk_read_fasta(const char* const* fasta_files, const char* const* fai_files, 
         G->device = device;
         for (uint64_t f = 0; f < n_files; f++) {
             if (!fasta_files[f] || (fai_files && !fai_files[f])) throw Error(JK_ERR_ARG, "NULL file name");
-            const std::vector<uint8_t> text = slurp_gz(fasta_files[f]);
+            HostText text;
+            slurp_gz(fasta_files[f], text);
             const FastaPlan plan = fai_files ? plan_ind(fai_files[f], text.size()) : plan_noind(text, cut_names != 0);
             fasta_pack_file(*G, text, plan, /*strip_cr=*/fai_files == nullptr, remove_soft_mask != 0, &G->ms);
         }
