@@ -46,7 +46,7 @@ JK_HD jk_pcg64 jk_pcg_seed(const uint32_t* w) {
 }
 
 // operator(): advance, then XSL-RR of the NEW state (128-bit engines have output_previous = false).
-JK_HD uint64_t jk_pcg_next(jk_pcg64& e) {
+JK_HD uint64_t jk_pcg_next_ref(jk_pcg64& e) {
     jk_u128 st = jk_mk128(e.s_hi, e.s_lo) * jk_mk128(JK_PCG_MULT_HI, JK_PCG_MULT_LO) + jk_mk128(e.inc_hi, e.inc_lo);
     uint64_t hi = (uint64_t)(st >> 64), lo = (uint64_t)st;
     e.s_hi = hi; e.s_lo = lo;
@@ -54,6 +54,61 @@ JK_HD uint64_t jk_pcg_next(jk_pcg64& e) {
     uint64_t x = hi ^ lo;
     return (x >> rot) | (x << ((64u - rot) & 63u));
 }
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JK_PCG_PLAIN)
+// The same step written for the gfx950 VALU.  The 128x128->128 multiply-add is the hot spot of every
+// generator kernel (~1 206 steps per read pair); the compiler's expansion of the __int128 expression
+// spends a third of its ~35 instructions on register moves and on a separate 4-instruction carry chain for
+// "+ increment".  Here the increment rides in the 64-bit addend of v_mad_u64_u32 and the two carries that
+// can leave bit 63 are taken from the instruction's carry-out (which plain C cannot name):
+//     t0 = s0*m0 + (c1:c0)           -> limb 0, carry cA (worth 2^64)
+//     t1 = s1*m0 + hi(t0); t1 += s0*m1 -> limb 1, carry cB (worth 2^96)
+//     h  = s2*m0 + (c3:c2) + s1*m1 + s0*m2 + hi(t1) + cA, hi(h) += lo32(s0*m3 + s1*m2 + s2*m1 + s3*m0) + cB
+// gfx940-family hazard: a VALU result in an SGPR (carry-out / vcc) needs 2 wait states before a VALU reads
+// it, and the compiler cannot see inside asm: the block below is ordered so that this always holds.
+__device__ __forceinline__ uint64_t jk_pcg_next(jk_pcg64& e) {
+    const uint32_t s0 = (uint32_t)e.s_lo, s1 = (uint32_t)(e.s_lo >> 32), s2 = (uint32_t)e.s_hi, s3 = (uint32_t)(e.s_hi >> 32);
+    const uint32_t m0 = (uint32_t)JK_PCG_MULT_LO, m1 = (uint32_t)(JK_PCG_MULT_LO >> 32);
+    const uint32_t m2 = (uint32_t)JK_PCG_MULT_HI, m3 = (uint32_t)(JK_PCG_MULT_HI >> 32);
+    uint64_t t0, t1, h, cA, cB, junk;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t0), "=s"(cA) : "v"(s0), "s"(m0), "v"(e.inc_lo));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(h), "=s"(junk) : "v"(s2), "s"(m0), "v"(e.inc_hi));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t1), "=s"(junk) : "v"(s1), "s"(m0), "v"(t0 >> 32));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(h), "=s"(junk) : "v"(s1), "s"(m1), "v"(h));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(t1), "=s"(cB) : "v"(s0), "s"(m1), "v"(t1));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(h), "=s"(junk) : "v"(s0), "s"(m2), "v"(h));
+    const uint32_t hu = (uint32_t)(h >> 32) + (s0 * m3 + s1 * m2 + s2 * m1 + s3 * m0);
+    const uint32_t n0 = (uint32_t)t0, n1 = (uint32_t)t1;
+    uint32_t h_lo, h_hi, x_lo;
+    // Wait states by construction: cA is at least two VALU instructions old when the first add reads it (the
+    // t1 and h chains depend on t0 and feed this add); cB may have been written by the instruction just
+    // before this block, so its add comes third; vcc is read two instructions after it is written.
+    asm("v_addc_co_u32_e64 %[hl], vcc, %[h0], %[t1h], %[cA]\n\t"
+        "v_xor_b32_e32 %[xl], %[n0], %[hl]\n\t"
+        "v_addc_co_u32_e64 %[hh], %[jk], %[hu], 0, %[cB]\n\t"
+        "v_addc_co_u32_e32 %[hh], vcc, 0, %[hh], vcc"
+        : [hl] "=&v"(h_lo), [hh] "=&v"(h_hi), [xl] "=&v"(x_lo), [jk] "=&s"(junk)
+        : [h0] "v"((uint32_t)h), [t1h] "v"((uint32_t)(t1 >> 32)), [cA] "s"(cA), [hu] "v"(hu), [cB] "s"(cB), [n0] "v"(n0)
+        : "vcc");
+    e.s_lo = ((uint64_t)n1 << 32) | n0;
+    e.s_hi = ((uint64_t)h_hi << 32) | h_lo;
+    // XSL-RR: rotate (hi ^ lo) right by the top 6 bits of the state; rot >= 32 swaps the two words
+    // (bit-select on the sign of the high word instead of compare + vcc + two selects)
+    const uint32_t x_hi = n1 ^ h_hi, rot = h_hi >> 26;
+    const uint32_t a = __builtin_amdgcn_alignbit(x_hi, x_lo, rot);      // (x >> (rot & 31)) low word
+    const uint32_t b = __builtin_amdgcn_alignbit(x_lo, x_hi, rot);      // ... high word
+    uint32_t sw, r_lo, r_hi;
+    asm("v_ashrrev_i32_e32 %[sw], 31, %[hh]\n\t"
+        "v_bfi_b32 %[rl], %[sw], %[b], %[a]\n\t"
+        "v_bfi_b32 %[rh], %[sw], %[a], %[b]"
+        : [sw] "=&v"(sw), [rl] "=&v"(r_lo), [rh] "=&v"(r_hi)
+        : [hh] "v"(h_hi), [a] "v"(a), [b] "v"(b));
+    return ((uint64_t)r_hi << 32) | r_lo;
+}
+__host__ inline uint64_t jk_pcg_next(jk_pcg64& e) { return jk_pcg_next_ref(e); }    // host code seen by the device pass
+#else
+JK_HD uint64_t jk_pcg_next(jk_pcg64& e) { return jk_pcg_next_ref(e); }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // runif_01(eng) = ((long double)x + 1) / ((long double)(2^64-1) + 2)  (src/pcg.h:99-101).

@@ -87,48 +87,88 @@ __device__ __forceinline__ uint64_t cut_point(double c, bool* all) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Line-staged appender: bytes -> 32-bit word in a register -> the lane's 128-byte line in LDS
-// (layout [word/4][thread][word%4], so a lane's 16-byte pieces are contiguous for ds_read_b128) ->
-// eight 16-byte global stores when the line is full.  Only the owning thread touches its LDS line.
+// Ring-staged appender: bytes -> 64-bit shift register -> 32-bit words in the lane's 128-byte LDS ring
+// (layout [piece][thread][word], a lane's 16-byte pieces are contiguous for ds_read_b128) -> 16-byte
+// global stores into the lane's contiguous pool region.  Only the owning thread touches its ring.
+//
+// In the per-position loop the lanes of a wave fill their rings at nearly the same rate (about one byte
+// per position), so flushing is done by the whole wave at once: when ANY lane's ring is nearly full,
+// EVERY lane writes out all of its complete 16-byte pieces (rs_flush under a wave-uniform branch).  A lane
+// flushing on its own whenever its private line fills (the first version) put a ~50-instruction
+// divergent block into ~40 % of all loop iterations; synchronised, the block runs once per ~110.
 // ---------------------------------------------------------------------------------------------
+// bits 0, 2, 4, ... 62 of v packed into bits 0..31
+__device__ __forceinline__ uint64_t _pext_even(uint64_t v) {
+    v &= 0x5555555555555555ULL;
+    v = (v | (v >> 1)) & 0x3333333333333333ULL;
+    v = (v | (v >> 2)) & 0x0f0f0f0f0f0f0f0fULL;
+    v = (v | (v >> 4)) & 0x00ff00ff00ff00ffULL;
+    v = (v | (v >> 8)) & 0x0000ffff0000ffffULL;
+    v = (v | (v >> 16)) & 0x00000000ffffffffULL;
+    return v;
+}
 constexpr int PB_BLOCK = 256;
-struct LineStream {
-    uint8_t* gp;       // global address of the line being filled (128-byte aligned)
-    uint32_t* lds;     // this thread's slot 0: lds[(w >> 2) * PB_BLOCK * 4 + (w & 3)] is word w of the line
-    uint32_t w;        // bytes gathered for the current word
-    uint32_t pos;      // byte offset in the lane's stream of the next byte
+struct RingStream {
+    uint8_t* gp;       // global address of the first byte not yet flushed (16-byte aligned)
+    uint32_t* lds;     // this thread's slot: word w of the ring is lds[(w >> 2) * PB_BLOCK * 4 + (w & 3)]
+    uint64_t acc;      // bytes not yet in the ring, oldest in the low byte
+    uint32_t nacc;     // their number (< 4 between calls)
+    uint32_t widx;     // ring index of the next word to write (0..31)
+    uint32_t pend;     // words in the ring (0..32); the oldest one starts a 16-byte piece
+    uint64_t pos;      // bytes appended so far
 };
-__device__ __forceinline__ void ls_flush_line(LineStream& s) {
+__device__ __forceinline__ uint32_t* rs_slot(const RingStream& s, uint32_t w) { return s.lds + (w >> 2) * PB_BLOCK * 4 + (w & 3u); }
+// write out every complete 16-byte piece of this lane's ring
+__device__ __forceinline__ void rs_flush(RingStream& s) {
+    const uint32_t np = s.pend >> 2;
+    const uint32_t first = ((s.widx - s.pend) & 31u) >> 2;
 #pragma unroll
-    for (uint32_t q = 0; q < 8; q++) {
-        const uint4 v = *reinterpret_cast<const uint4*>(s.lds + q * PB_BLOCK * 4);
-        *reinterpret_cast<uint4*>(s.gp + q * 16) = v;
+    for (uint32_t k = 0; k < 8; k++) {
+        if (k < np) {
+            const uint4 v = *reinterpret_cast<const uint4*>(s.lds + ((first + k) & 7u) * PB_BLOCK * 4);
+            *reinterpret_cast<uint4*>(s.gp + k * 16) = v;
+        }
     }
-    s.gp += 128;
+    s.gp += np * 16;
+    s.pend -= np * 4;
 }
-__device__ __forceinline__ void ls_word_done(LineStream& s) {       // pos is a multiple of 4 here
-    const uint32_t wi = ((s.pos >> 2) - 1u) & 31u;
-    s.lds[(wi >> 2) * PB_BLOCK * 4 + (wi & 3u)] = s.w;
-    s.w = 0;
-    if (wi == 31u) ls_flush_line(s);
+// move one word from the shift register to the ring if there is one (the ring must have room)
+__device__ __forceinline__ void rs_drain(RingStream& s) {
+    if (s.nacc >= 4u) {
+        *rs_slot(s, s.widx) = (uint32_t)s.acc;
+        s.acc >>= 32; s.nacc -= 4u;
+        s.widx = (s.widx + 1u) & 31u; s.pend++;
+    }
 }
-__device__ __forceinline__ void ls_put(LineStream& s, uint32_t byte) {
-    s.w |= byte << (8u * (s.pos & 3u));
-    s.pos++;
-    if ((s.pos & 3u) == 0) ls_word_done(s);
+// append `n` (0..2) bytes given in the low bytes of `two`; the caller keeps the ring from overflowing
+// (one word at most is produced per call)
+__device__ __forceinline__ void rs_put2(RingStream& s, uint32_t two, uint32_t n) {
+    s.acc |= (uint64_t)two << (8u * s.nacc);
+    s.nacc += n; s.pos += n;
+    rs_drain(s);
 }
-__device__ __forceinline__ void ls_fill(LineStream& s, uint32_t byte, uint64_t count) {
-    while (count && (s.pos & 3u)) { ls_put(s, byte); count--; }
+// general-purpose append (headers, separators): checks for room itself
+__device__ __forceinline__ void rs_put(RingStream& s, uint32_t byte) {
+    if (s.pend >= 31u) rs_flush(s);
+    rs_put2(s, byte, 1u);
+}
+__device__ __forceinline__ void rs_fill(RingStream& s, uint32_t byte, uint64_t count) {
+    while (count && s.nacc) { rs_put(s, byte); count--; }
     const uint32_t word = byte * 0x01010101u;
-    while (count >= 4) { s.w = word; s.pos += 4; ls_word_done(s); count -= 4; }
-    while (count) { ls_put(s, byte); count--; }
+    while (count >= 4) {
+        if (s.pend >= 32u) rs_flush(s);
+        *rs_slot(s, s.widx) = word;
+        s.widx = (s.widx + 1u) & 31u; s.pend++; s.pos += 4;
+        count -= 4;
+    }
+    while (count) { rs_put(s, byte); count--; }
 }
-// end of the lane's stream: write the partial line (whole words from LDS, then the pending bytes)
-__device__ __forceinline__ void ls_finish(LineStream& s) {
-    const uint32_t nw = (s.pos >> 2) & 31u;
-    for (uint32_t wi = 0; wi < nw; wi++)
-        *reinterpret_cast<uint32_t*>(s.gp + wi * 4) = s.lds[(wi >> 2) * PB_BLOCK * 4 + (wi & 3u)];
-    for (uint32_t j = 0; j < (s.pos & 3u); j++) s.gp[nw * 4 + j] = (uint8_t)(s.w >> (8u * j));
+// end of the lane's stream: complete pieces, then the remaining words and bytes one by one
+__device__ __forceinline__ void rs_finish(RingStream& s) {
+    rs_flush(s);
+    const uint32_t first = (s.widx - s.pend) & 31u;
+    for (uint32_t k = 0; k < s.pend; k++) *reinterpret_cast<uint32_t*>(s.gp + k * 4) = *rs_slot(s, (first + k) & 31u);
+    for (uint32_t j = 0; j < s.nacc; j++) s.gp[s.pend * 4 + j] = (uint8_t)(s.acc >> (8u * j));
 }
 
 template <bool HAP>
@@ -153,10 +193,10 @@ pacbio_kernel(PacbioKernelParams P) {
     const uint32_t tile = lane >> 6;
     const uint64_t tile_off = P.pool_off[tile];
     const uint64_t lane_cap = (P.pool_off[tile + 1] - tile_off) >> 6;      // a multiple of 128 (host)
-    LineStream o;
+    RingStream o;
     o.gp = P.pool + tile_off + (uint64_t)(lane & 63u) * lane_cap;           // this lane's contiguous region
     o.lds = stage + threadIdx.x * 4;
-    o.w = 0; o.pos = 0;
+    o.acc = 0; o.nacc = 0; o.widx = 0; o.pend = 0; o.pos = 0;
 
     uint32_t err = 0;
     const size_t ev_stride = (size_t)P.n_lanes;
@@ -329,7 +369,7 @@ pacbio_kernel(PacbioKernelParams P) {
             {
                 uint32_t hdr_len = P.g.hdr_off[ci + 1] - P.g.hdr_off[ci];
                 if ((uint64_t)o.pos + hdr_len + 24 + 2 * L + 8 > lane_cap) { err |= JK_KERR_POOL_OVERFLOW; break; }
-                for (uint32_t h = P.g.hdr_off[ci]; h < P.g.hdr_off[ci + 1]; h++) ls_put(o, P.g.hdr_blob[h]);
+                for (uint32_t h = P.g.hdr_off[ci]; h < P.g.hdr_off[ci + 1]; h++) rs_put(o, P.g.hdr_blob[h]);
                 uint64_t v = read_start, packed_lo = 0, packed_hi = 0; uint32_t nd = 0;
                 do {
                     const uint64_t q = v / 10, d = v - q * 10;
@@ -338,12 +378,12 @@ pacbio_kernel(PacbioKernelParams P) {
                     v = q; nd++;
                 } while (v);
                 for (uint32_t d = 0; d < nd; d++) {
-                    ls_put(o, '0' + (uint32_t)(packed_lo & 15u));
+                    rs_put(o, '0' + (uint32_t)(packed_lo & 15u));
                     packed_lo = (packed_lo >> 4) | (packed_hi << 60); packed_hi >>= 4;
                 }
-                ls_put(o, '-');
-                ls_put(o, reverse ? 'R' : 'F');
-                ls_put(o, '\n');
+                rs_put(o, '-');
+                rs_put(o, reverse ? 'R' : 'F');
+                rs_put(o, '\n');
             }
             // source walker: read[p] = forward chrom[start + p], reverse cmp(chrom[start + space - 1 - p])
             const uint8_t* const gseq = P.g.seq;
@@ -381,44 +421,77 @@ pacbio_kernel(PacbioKernelParams P) {
             if (space > 0) seg_enter(0);
 
             // ---- pass 2: emit bases
-            // The four cases (plain / insertion / deletion / substitution) are folded into one straight-line
-            // body: with 64 lanes almost every position has some lane in each case, so separate branches would
-            // all be executed at every position.  The extra draw is computed for every lane on a copy of the
-            // engine and only committed by lanes whose position is an insertion or a substitution.
-            uint64_t cur2 = 0, p2 = 0, evw = 0;
+            // Positions are handled 32 at a time (one word of event codes).  Per word the lane first finds
+            // how many of its positions it will process (the read ends when cur2 reaches L), makes the
+            // draws of the insertions and substitutions among them -- a wave-uniform loop over "the j-th
+            // event of my word", so the wave pays for max-over-lanes draws instead of one per position --
+            // and parks each result (2 bits) at its position.  The per-position loop then only moves bytes.
+            uint64_t cur2 = 0, p2 = 0;
             while (cur2 < L) {
-                if ((p2 & 31u) == 0) evw = (p2 < pos) ? evl[(p2 >> 5) * ev_stride] : 0;
-                const uint32_t type = (p2 < pos) ? (uint32_t)(evw >> (2u * (p2 & 31u))) & 3u : 0u;
+                const uint64_t evw = (p2 < pos) ? evl[(p2 >> 5) * ev_stride] : 0;
+                const uint32_t lo = (uint32_t)_pext_even(evw), hi = (uint32_t)_pext_even(evw >> 1);   // bit k: code bit 0 / 1 of position k
+                const uint32_t insm = lo & ~hi, delm = hi & ~lo;
+                // smallest k in [0, 32] with cur2 + k + #ins(<k) - #del(<k) >= L (monotone in k): positions < k are processed
+                uint32_t kcut;
+                {
+                    uint32_t a = 0;                    // invariant: f(a) < L
+                    const uint64_t need = L - cur2;    // > 0
+#pragma unroll
+                    for (uint32_t step = 16; step > 0; step >>= 1) {
+                        const uint32_t k = a + step;
+                        const uint32_t below = (1u << k) - 1u;          // k <= 31 here
+                        const uint64_t f = (uint64_t)k + __popc(insm & below) - __popc(delm & below);
+                        a = (f < need) ? k : a;
+                    }
+                    // a = largest k in [0, 31] with f(k) < need; position a is processed, a + 1 may be the cut
+                    kcut = a + 1u;
+                }
+                const uint32_t proc = kcut >= 32u ? 0xffffffffu : ((1u << kcut) - 1u);
+                // draws of this word's events, in position order (src/hts_pacbio.cpp:430-457)
+                uint32_t evm = lo & proc;              // code 1 (insertion) or 3 (substitution)
+                uint64_t res = 0; uint32_t nul = 0;
+                while (__builtin_amdgcn_ballot_w64(evm != 0u)) {
+                    if (evm) {
+                        const uint32_t k = (uint32_t)__builtin_ctz(evm);
+                        evm &= evm - 1u;
+                        const uint64_t x = rng();
+                        uint32_t code;
+                        if ((hi >> k) & 1u) code = runif_index32(x, 3);                    // mm_nucleos[nt][(uint64)(runif_01 * 3)]
+                        else code = (uint32_t)jk_runif_index(x, 4);                        // jlp::bases[(uint64)(runif_01 * 4)]
+                        const bool is_nul = ((hi >> k) & 1u) ? (code >= 3u) : (code >= 4u); // index past the string: its NUL
+                        nul |= is_nul ? (1u << k) : 0u;
+                        res |= (uint64_t)(code & 3u) << (2u * k);
+                    }
+                }
                 // the reference would read stale buffer bytes past the read's window here (only reachable when a
                 // read is as long as its chromosome); refuse instead of inventing bytes
-                if (p2 >= space) { err |= JK_KERR_PB_SPACE; break; }
-                if (HAP && p2 >= seg_end) seg_enter(p2);
-                const uint32_t c = src_next();
-                // character of read[p2] as the reference sees it (cmp_map for the reverse strand)
-                const bool is_nt = c < 4u;
-                const uint32_t nt = is_nt ? (reverse ? (c ^ 2u) : c) : 4u;
-                const uint32_t ch = is_nt ? base_char(nt) : (reverse ? (c == 'N' ? (uint32_t)'N' : 0u) : c);
-                jk_pcg64 e2 = rng.e;
-                const uint64_t x = jk_pcg_next(e2);
-                const bool is_ins = type == 1u, is_del = type == 2u, is_sub = type == 3u;
-                if (is_ins | is_sub) rng.e = e2;                       // only these cases consume a draw
-                const uint32_t r4 = (uint32_t)jk_runif_index(x, 4);    // insertion: jlp::bases[(uint64)(runif_01 * 4)]
-                const uint32_t m = runif_index32(x, 3);                // substitution: mm_nucleos[nt][(uint64)(runif_01 * 3)]
-                const uint32_t ins_ch = r4 < 4u ? base_char(r4) : 0u;
-                const uint32_t sub_ch = (m < 3u) ? (is_nt ? base_char(m + (m >= nt ? 1u : 0u)) : (uint32_t)'N') : 0u;
-                const uint32_t b0 = is_sub ? sub_ch : ch;
-                const uint32_t nb = is_del ? 0u : (is_ins ? 2u : 1u);
-                const uint32_t two = b0 | (ins_ch << 8);
-                if (nb >= 1u) ls_put(o, two & 0xffu);
-                if (nb == 2u) ls_put(o, two >> 8);
-                cur2 += nb;
-                p2++;
+                if (p2 + kcut > space) { err |= JK_KERR_PB_SPACE; break; }
+                for (uint32_t k = 0; k < kcut; k++) {                 // (lanes near the end of their read run fewer)
+                    if (__builtin_amdgcn_ballot_w64(o.pend >= 31u)) rs_flush(o);
+                    if (HAP && p2 + k >= seg_end) seg_enter(p2 + k);
+                    const uint32_t c = src_next();
+                    // character of read[p2 + k] as the reference sees it (cmp_map for the reverse strand)
+                    const bool is_nt = c < 4u;
+                    const uint32_t nt = is_nt ? (reverse ? (c ^ 2u) : c) : 4u;
+                    const uint32_t ch = is_nt ? base_char(nt) : (reverse ? (c == 'N' ? (uint32_t)'N' : 0u) : c);
+                    const uint32_t b0bit = (lo >> k) & 1u, b1bit = (hi >> k) & 1u;
+                    const bool is_ins = b0bit && !b1bit, is_del = !b0bit && b1bit, is_sub = b0bit && b1bit;
+                    const uint32_t code = (uint32_t)(res >> (2u * k)) & 3u;
+                    const bool is_nul = (nul >> k) & 1u;
+                    const uint32_t ins_ch = is_nul ? 0u : base_char(code);
+                    const uint32_t sub_ch = is_nul ? 0u : (is_nt ? base_char(code + (code >= nt ? 1u : 0u)) : (uint32_t)'N');
+                    const uint32_t b0 = is_sub ? sub_ch : ch;
+                    const uint32_t nb = is_del ? 0u : (is_ins ? 2u : 1u);
+                    rs_put2(o, is_del ? 0u : (b0 | (is_ins ? (ins_ch << 8) : 0u)), nb);
+                    cur2 += nb;
+                }
+                p2 += kcut;
             }
             if (err) break;
-            ls_put(o, '\n'); ls_put(o, '+'); ls_put(o, '\n');
-            ls_fill(o, qual_left, split_pos < L ? split_pos : L);
-            ls_fill(o, qual_right, split_pos < L ? L - split_pos : 0);
-            ls_put(o, '\n');
+            rs_put(o, '\n'); rs_put(o, '+'); rs_put(o, '\n');
+            rs_fill(o, qual_left, split_pos < L ? split_pos : L);
+            rs_fill(o, qual_right, split_pos < L ? L - split_pos : 0);
+            rs_put(o, '\n');
         }
         if (HAP) ccnt = ccnt > 0 ? ccnt - 1 : 0;     // n_reads_vc[hap][chr]-- (one_read) / if > 0 (re_read)
 
@@ -429,7 +502,7 @@ pacbio_kernel(PacbioKernelParams P) {
         if (dup && made < quota && in_pool < P.pool_size) is_dup = true;
         else { is_dup = false; if (in_pool >= P.pool_size || made >= quota) in_pool = 0; }
     }
-    ls_finish(o);
+    rs_finish(o);
     P.lane_bytes[lane] = o.pos;
     if (o.pos > lane_cap) err |= JK_KERR_POOL_OVERFLOW;
     P.lane_made[lane] = made;

@@ -20,8 +20,25 @@ __global__ void __launch_bounds__(1024) k(uint64_t* out, int n_steps) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+// the hand-scheduled device step against the plain __int128 expression, 2^14 lanes x 4096 steps
+__global__ void check(uint32_t* bad) {
+    uint32_t w[8];
+    for (int i = 0; i < 8; i++) w[i] = (threadIdx.x + blockIdx.x * blockDim.x) * 2654435761u + i * 40503u;
+    jk_pcg64 a = jk_pcg_seed(w), b = a;
+    for (int i = 0; i < 4096; i++) {
+        const uint64_t x = jk_pcg_next(a), y = jk_pcg_next_ref(b);
+        if (x != y || a.s_hi != b.s_hi || a.s_lo != b.s_lo) atomicAdd(bad, 1u);
+    }
+}
+
 int main() {
     uint64_t* d; hipMalloc(&d, 8 << 20);
+    {
+        uint32_t* bad; hipMalloc(&bad, 4); hipMemset(bad, 0, 4);
+        hipLaunchKernelGGL(check, dim3(64), dim3(256), 0, 0, bad);
+        uint32_t h = 1; hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
+        printf("asm step vs __int128 step: %u mismatches\n", h);
+    }
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     const int steps = 20000, blocks = 1024;   // 1M lanes
     for (int mode = 0; mode < 3; mode++) {
