@@ -157,7 +157,7 @@ static void upload_genome(jk_session& s, const jk_ref_genome& g, const char* blo
     JK_HIP(hipDeviceSynchronize());
     uint32_t bad_h = 0;
     JK_HIP(hipMemcpy(&bad_h, bad.p, 4, hipMemcpyDeviceToHost));
-    if (bad_h) throw Error(JK_ERR_UNSUPPORTED, "the genome contains bytes 0x00-0x03, which the GPU path cannot represent");
+    if (bad_h) throw Error(JK_ERR_UNSUPPORTED, "the genome contains bytes 0xfc-0xff, which the GPU path cannot represent");
     s.d_chrom_off.upload(off);
     s.d_chrom_len.upload(len);
     s.n_chroms = (uint32_t)g.n_chroms;

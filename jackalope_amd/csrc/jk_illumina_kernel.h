@@ -565,15 +565,21 @@ illumina_kernel(IlluminaKernelParams P) {
 }
 
 // ASCII -> code, in place (run once per uploaded buffer): T,C,A,G -> 0..3 (jlp::bases order, complement =
-// code ^ 2); every other byte keeps its ASCII value (>= 4), which is all the Illumina path needs to know
-// ("not TCAG") and what the PacBio path copies through verbatim.  Input bytes 0..3 cannot be represented.
+// code ^ 2); every other byte keeps its value (>= 4), which is all the Illumina path needs to know
+// ("not TCAG") and what the PacBio path copies through verbatim.  Input bytes 0..3 -- 0 is what the
+// reference's FASTA reader turns every non-TCAGN character into (src/str_manip.h:24-56) -- move to
+// 0xfc..0xff (jk_decode_other undoes it); input bytes 0xfc..0xff cannot be represented.
+constexpr uint32_t JK_LOW_BYTE_BASE = 0xfcu;
+__device__ __forceinline__ uint32_t jk_decode_other(uint32_t code) {       // code >= 4
+    return code >= JK_LOW_BYTE_BASE ? code - JK_LOW_BYTE_BASE : code;
+}
 __global__ void encode_bases_kernel(uint8_t* seq, uint64_t n, uint32_t* bad) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t k = i; k < n; k += stride) {
         const uint8_t c = seq[k];
-        if (c < 4) *bad = 1;
-        seq[k] = c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : c;
+        if (c >= JK_LOW_BYTE_BASE) *bad = 1;
+        seq[k] = c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : (c < 4 ? (uint8_t)(JK_LOW_BYTE_BASE + c) : c);
     }
 }
 

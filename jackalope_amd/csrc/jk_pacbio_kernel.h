@@ -473,7 +473,7 @@ pacbio_kernel(PacbioKernelParams P) {
                     // character of read[p2 + k] as the reference sees it (cmp_map for the reverse strand)
                     const bool is_nt = c < 4u;
                     const uint32_t nt = is_nt ? (reverse ? (c ^ 2u) : c) : 4u;
-                    const uint32_t ch = is_nt ? base_char(nt) : (reverse ? (c == 'N' ? (uint32_t)'N' : 0u) : c);
+                    const uint32_t ch = is_nt ? base_char(nt) : (reverse ? (c == 'N' ? (uint32_t)'N' : 0u) : jk_decode_other(c));
                     const uint32_t b0bit = (lo >> k) & 1u, b1bit = (hi >> k) & 1u;
                     const bool is_ins = b0bit && !b1bit, is_del = !b0bit && b1bit, is_sub = b0bit && b1bit;
                     const uint32_t code = (uint32_t)(res >> (2u * k)) & 3u;

@@ -104,6 +104,28 @@ def test_unordered_index_and_sequencing_from_the_file(ja, O, tmp_path):
         assert dev == (s.fetch(0), s.fetch(1))
 
 
+def test_iupac_codes_read_and_sequence_like_the_reference(ja, O, tmp_path):
+    """Non-TCAGN characters become zero bytes in read_fasta (src/str_manip.h:24-56); the sequencers then see a
+    non-TCAG base ('N' with a random quality in Illumina reads, copied through by PacBio)."""
+    rng = np.random.default_rng(12)
+    seq = bytes(np.frombuffer(b"TCAGTCAGTCAGNRYMKtcag", dtype=np.uint8)[rng.integers(0, 21, size=60_000)])
+    fn = str(tmp_path / "iupac.fa")
+    write_fasta(fn, ["c1"], [seq])
+    g = same(ja, O, [fn])
+    host = ja.RefGenome([g.chrom(0)], names=g.names)
+    assert 0 in host.seqs[0]
+    T, n = 8, 1500
+    words = ja.seed_words(8, 16 * T)
+    p1, p2 = ja.read_profile(None, None, 150, 1), ja.read_profile(None, None, 150, 2)
+    j = job()
+    o1, o2, _ = O.illumina_ref(host, paired=True, n_reads=n, prob_dup=j["prob_dup"], n_threads=T, read_pool_size=1000,
+                               shape=16.0, scale=25.0, fmin=150, fmax=2 ** 32 - 1, prof1=p1, prof2=p2, ins1=j["ins_prob1"],
+                               del1=j["del_prob1"], ins2=j["ins_prob2"], del2=j["del_prob2"], words=words)
+    with ja.illumina(g, None, n, 150, True, n_threads=T, seed_words=words, _session=True) as s:
+        s.generate()
+        assert (s.fetch(0), s.fetch(1)) == (o1, o2)
+
+
 def test_errors(ja, tmp_path):
     with pytest.raises(ValueError, match="argument `fasta_files` must be a character vector"):
         ja.read_fasta([])

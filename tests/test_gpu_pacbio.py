@@ -62,7 +62,7 @@ def test_other_error_models(ja, O):
 
 def test_non_tcag_bases_are_copied_like_the_reference(ja, O):
     rng = np.random.default_rng(45)
-    seq = np.frombuffer(b"TCAGTCAGTCAGNnRY-", dtype=np.uint8)[rng.integers(0, 17, size=250_000)]
+    seq = np.frombuffer(b"TCAGTCAGTCAGNnRY-\x00\x03", dtype=np.uint8)[rng.integers(0, 19, size=250_000)]
     g = ja.RefGenome([seq])
     check_ref(ja, O, g, 200, 6, {"custom_read_lengths": [800, 3000]})
 

@@ -90,6 +90,12 @@ def test_non_tcag_bases(ja, O):
     g = ja.RefGenome([seq, "C" * 25 + "N" * 150 + "T" * 25])
     check(ja, O, g, 150, 4000, 21, job())
     check(ja, O, g, 150, 2000, 4, job(matepair=True))
+    # zero bytes are what the reference's FASTA reader makes of every non-TCAGN character; bytes 1..3 ride along
+    low = np.frombuffer(b"TCAGTCAGN\x00\x01\x02\x03", dtype=np.uint8)[rng.integers(0, 13, size=30_000)]
+    check(ja, O, ja.RefGenome([low]), 150, 3000, 9, job())
+    with pytest.raises(ja.JackalopeHipError, match="0xfc-0xff"):
+        ja.illumina(ja.RefGenome([np.full(1000, 0xfd, dtype=np.uint8)]), None, 10, 150, True, n_threads=1,
+                    seed_words=ja.seed_words(1, 16), _session=True)
 
 
 @pytest.mark.parametrize("ins,dele", [(0.05, 0.05), (0.2, 0.0), (0.0, 0.3), (0.3, 0.3), (0.0, 0.0)])
