@@ -233,7 +233,7 @@ def create_genome_main(a):
                         "frac": round(bases / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "create_genome_kernel",
                         "launches_per_step": 1, "kernel_ms": round(kern_s * 1e3, 3),
                         "note": "1 byte written per base; integer-ALU bound: 2 pcg64 outputs per base (%.3g outputs/s "
-                                "against the measured 1.38e12/s ceiling)" % (2 * bases / kern_s)}}
+                                "against the measured 1.45e12/s ceiling)" % (2 * bases / kern_s)}}
     if not a.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
@@ -423,7 +423,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "algorithmic_bytes_per_pair": round(alg_bytes * n_launch / max(pairs_rank, 1), 2),
                          "note": "integer-ALU bound: ~1206 pcg64 steps (128-bit multiply) per pair, "
-                                 "%.3g draws/s against a measured pure-pcg ceiling of 1.38e12 draws/s/GPU; "
+                                 "%.3g draws/s against a measured pure-pcg ceiling of 1.45e12 draws/s/GPU; "
                                  "traffic = (2*FETCH_SIZE + WRITE_SIZE) of the committed rocprofv3 --pmc passes "
                                  "(profiles/), null when they were taken at another launch size"
                                  % (1206.0 * pairs_rank / n_launch / kern_s)},

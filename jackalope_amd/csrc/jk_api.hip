@@ -75,6 +75,10 @@ struct Batch {
 
 }  // namespace jk
 
+#ifndef JK_ILL_BLOCK
+#define JK_ILL_BLOCK 1024     // threads per generator workgroup (one workgroup per CU when the tables sit in LDS)
+#endif
+
 using namespace jk;
 
 struct jk_session {
@@ -346,10 +350,10 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
 
     if (s.lds_tables) {
         const int lb = (int)s.lds_bytes;
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, 1024, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, JK_ILL_BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, JK_ILL_BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
     }
 }
 
@@ -865,12 +869,15 @@ static void launch_generate(jk_session& s) {
         }
         P.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
         P.chrom_stride = (uint32_t)s.n_shard;
-        const uint32_t block = 1024;
+#ifndef JK_ILL_BLOCK
+#define JK_ILL_BLOCK 1024
+#endif
+        const uint32_t block = JK_ILL_BLOCK;
         const uint32_t grid = (B.n_lanes + block - 1) / block;
         // the pool set is free again once the compaction of batch b-2 has read it
         if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));
         JK_HIP(hipEventRecord(s.events[ev++], s.stream));
-#define JK_LAUNCH(LDS, NE, HAP, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, 1024, HAP>), dim3(grid), dim3(block), SH, s.stream, P)
+#define JK_LAUNCH(LDS, NE, HAP, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP>), dim3(grid), dim3(block), SH, s.stream, P)
         if (s.lds_tables) {
             if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(true, 2, true, s.lds_bytes); else JK_LAUNCH(true, 1, true, s.lds_bytes); }
             else       { if (s.n_ends == 2) JK_LAUNCH(true, 2, false, s.lds_bytes); else JK_LAUNCH(true, 1, false, s.lds_bytes); }

@@ -56,7 +56,61 @@ def known_answers():
     }
 
 
+def pcg_advance_vectors():
+    """engine::advance of the reference (pcg_random.hpp:419-434): seed, jump, 8 outputs."""
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libref_pcg.so"))
+    out = []
+    for row, steps in [([1, 2, 3, 4, 5, 6, 7, 8], s) for s in (0, 1, 63, 64, 4096, 2 * 2048 * 977, (1 << 40) + 5, (1 << 64) - 1)] + \
+                      [([0xDEADBEEF, 0x01234567, 0x89ABCDEF, 0x0BADF00D, 0xCAFEF00D, 0xD15EA5E5, 1, 0x80000000], s)
+                       for s in (12345678901, 250_000_000)]:
+        w = np.asarray(row, dtype=np.uint32)
+        o = np.zeros(8, dtype=np.uint64)
+        lib.ref_pcg64_advance_outputs(w.ctypes.data_as(C.c_void_p), C.c_uint64(0), C.c_uint64(steps), C.c_uint64(8),
+                                      o.ctypes.data_as(C.c_void_p))
+        out.append({"sub_seeds": [int(x) for x in row], "steps": str(steps), "outputs": ["%016x" % int(x) for x in o]})
+    return {"source": "pcg64::advance of /root/reference/inst/include/pcg/pcg_random.hpp:419-434 via oracle/ref_pcg_driver.cpp",
+            "cases": out}
+
+
+def vcf_io_fixture():
+    """Edits and outcome of /root/reference/tests/testthat/test-vcf_IO.R:14-90 as data (1-based, as the R methods take them)."""
+    e1 = [["sub", 1, 6, "T"], ["sub", 2, 6, "A"], ["sub", 3, 6, "A"], ["sub", 3, 7, "T"], ["sub", 4, 6, "G"], ["sub", 4, 8, "T"],
+          ["del", 1, 7, 1], ["del", 2, 7, 2], ["del", 4, 9, 1], ["del", 1, 1, 3], ["del", 2, 2, 3], ["del", 3, 1, 3], ["del", 4, 3, 2]]
+    e2 = [["del", 1, 9, 1], ["ins", 1, 8, "A"], ["sub", 1, 6, "A"], ["sub", 2, 6, "A"], ["sub", 3, 6, "T"], ["del", 4, 6, 1],
+          ["ins", 1, 5, "TT"], ["ins", 2, 5, "TT"], ["ins", 3, 5, "T"], ["ins", 4, 5, "C"], ["sub", 4, 3, "T"],
+          ["ins", 2, 2, "AG"], ["del", 3, 2, 2], ["ins", 4, 2, "AG"], ["del", 1, 1, 1]]
+    vcf = {"1": [[1, "TCAG", ["G", "T", "TC"], [1, 2, 1, 3]], [6, "CAGT", ["TGT", "AT", "ATGT", "GAT"], [1, 2, 3, 4]]],
+           "2": [[1, "TCA", ["CA", "TCAGA", "T", "TCAGT"], [1, 2, 3, 4]], [5, "TC", ["TTTA", "TTT"], [1, 1, 2, 0]],
+                 [8, "GT", ["GA"], [1, 0, 0, 0]]]}
+    return {"source": "/root/reference/tests/testthat/test-vcf_IO.R:14-90", "chromosome": "TCAGTCAGTC", "n_haps": 4,
+            "edits": {"1": e1, "2": e2}, "vcf_rows_pos_ref_alts_genotypes": vcf}
+
+
+def oracle_digests():
+    """sha256 of the FASTQ this repo's CPU oracle writes for a few small jobs.  NOT reference output (the
+    reference cannot be built here): a regression anchor that both the oracle and the HIP path must keep hitting."""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import oracle_lib as O
+    import jackalope_amd as ja
+    from golden_jobs import JOBS, run_oracle
+    out = {}
+    for name in JOBS:
+        r1, r2 = run_oracle(ja, O, name)
+        out[name] = {"R1_sha256": hashlib.sha256(r1).hexdigest(), "R1_bytes": len(r1), "R1_head": r1[:160].decode(),
+                     "R2_sha256": hashlib.sha256(r2).hexdigest() if r2 is not None else None}
+    return {"source": "oracle/jk_oracle.cpp (this repo's CPU restatement), jobs defined in tests/golden_jobs.py", "jobs": out}
+
+
 if __name__ == "__main__":
+    with open(os.path.join(HERE, "pcg64_advance_vectors.json"), "w") as fh:
+        json.dump(pcg_advance_vectors(), fh, indent=1)
+    with open(os.path.join(HERE, "vcf_io_mutations.json"), "w") as fh:
+        json.dump(vcf_io_fixture(), fh, indent=1)
+    with open(os.path.join(HERE, "oracle_fastq_digests.json"), "w") as fh:
+        json.dump(oracle_digests(), fh, indent=1)
     with open(os.path.join(HERE, "pcg64_vectors.json"), "w") as fh:
         json.dump(pcg_vectors(), fh, indent=1)
     with open(os.path.join(HERE, "sequencer_known_answers.json"), "w") as fh:
