@@ -1182,6 +1182,13 @@ JK_HD void eval_one(int what, const uint64_t* in, uint64_t i, uint64_t aux, uint
             out[i] = jk_d2u(jk_runif_ab(in[4 * i], jk_x87_from_double(jk_u2d(in[4 * i + 1])), c));
             break;
         }
+        case JK_OP_RUNIF_INDEX32:          // the kernels' 32-bit form of RUNIF_INDEX (n < 2^32), device only
+#if defined(__HIP_DEVICE_COMPILE__)
+            out[i] = runif_index32(in[i], (uint32_t)aux);
+#else
+            out[i] = jk_runif_index(in[i], aux);
+#endif
+            break;
         default: break;
     }
 }

@@ -153,10 +153,14 @@ __device__ __forceinline__ uint32_t runif_index32(uint64_t x, uint32_t n) {
     const uint64_t t1 = (uint64_t)(uint32_t)(x >> 32) * n + (t0 >> 32);  // (x+1)*n = t1 * 2^32 + lo32(t0)
     uint32_t hi = (uint32_t)(t1 >> 32);
     // x87 rounding of the product can only carry into `hi` when the low 64 bits are within 2^31 of 2^64
-    if ((uint32_t)t1 == 0xffffffffu && hi != 0) {
-        const uint64_t lo = (t1 << 32) | (uint32_t)t0;
-        const uint64_t half = 1ULL << (31 - __builtin_clz(hi));
-        if (lo + half < lo) hi++;
+    // (probability 2^-32 per draw): one compare and a wave-uniform branch on the common path
+    if (__builtin_amdgcn_ballot_w64((uint32_t)t1 == 0xffffffffu) != 0) {
+        asm volatile("" ::: "memory");       // keeps the block from being if-converted into the common path
+        if ((uint32_t)t1 == 0xffffffffu && hi != 0) {
+            const uint64_t lo = (t1 << 32) | (uint32_t)t0;
+            const uint64_t half = 1ULL << (31 - __builtin_clz(hi));
+            if (lo + half < lo) hi++;
+        }
     }
     return hi;
 }

@@ -26,6 +26,18 @@ def test_runif_index(O, built, n):
     assert (dev_eval(_abi.OP_RUNIF_INDEX, x, n) == O.eval_many(_abi.OP_RUNIF_INDEX, x, n)).all()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 10, 33, 41, 100, 255])
+def test_runif_index_32bit_kernel_form(O, built, n):
+    """runif_index32 (what the per-base loops call), including inputs whose product lands within a few units of a
+    multiple of 2^64 -- the only place where the x87 rounding can carry (a wave-uniform rare branch in the kernel)."""
+    x = raw_inputs(500_000, seed=300 + n)
+    k = np.arange(1, n + 1, dtype=object)
+    near = np.array([int(v) for kk in k for v in (((int(kk) << 64) + d) // n - 1 for d in range(-2 * n, 2 * n + 1)) if 0 <= v < 2 ** 64],
+                    dtype=np.uint64)
+    x = np.concatenate([x, near])
+    assert (dev_eval(_abi.OP_RUNIF_INDEX32, x, n) == O.eval_many(_abi.OP_RUNIF_INDEX, x, n)).all()
+
+
 @pytest.mark.parametrize("what", [_abi.OP_RUNIF_DOUBLE, _abi.OP_CANONICAL, _abi.OP_N_QUAL, _abi.OP_LT_HALF])
 def test_unary_conversions(O, built, what):
     x = raw_inputs(4_000_000, seed=200 + what)
