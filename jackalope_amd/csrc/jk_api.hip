@@ -95,7 +95,8 @@ struct jk_session {
     IlluminaTables tables;
     DevBuf d_info, d_thresh, d_quals, d_mm;
     bool lds_tables = false;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, lds_launch = 0;
+    uint32_t lds_seg_off = 0;
     bool hap = false;
     int compress = 0;          // 0 = plain FASTQ, 1..9 = compression level
     bool bgzip = true;         // comp_method: "bgzip" (BGZF blocks) or "gzip"
@@ -333,7 +334,11 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     s.d_evw.alloc((size_t)s.n_ends * 4 * s.ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
 
     s.lds_bytes = (s.tables.thresh.size() + (s.tables.thresh.size() & 1)) * 8 + 256 * 8 + s.tables.info.size() * 4 + align_up(s.tables.quals.size() * 2, 16);
-    s.lds_tables = s.lds_bytes <= 150 * 1024;
+    // haplotype runs add the per-lane segment table (4 segments x 12 bytes x 1024 lanes) after the tables
+    const size_t seg_bytes = s.hap ? (size_t)4 * 12 * JK_ILL_BLOCK : 0;
+    s.lds_tables = s.lds_bytes + seg_bytes <= 158 * 1024;
+    s.lds_seg_off = s.lds_tables ? (uint32_t)align_up(s.lds_bytes, 16) : 0;
+    s.lds_launch = (s.lds_tables ? align_up(s.lds_bytes, 16) : 0) + seg_bytes;
 
     IlluminaKernelParams& P = s.kp;
     P.g.seq = s.d_seq.as<uint8_t>();
@@ -348,12 +353,18 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     P.quals = s.d_quals.as<uint16_t>(); P.mm_thresh = s.d_mm.as<uint64_t>();
     P.n_info = (uint32_t)s.tables.info.size(); P.n_entries = (uint32_t)s.tables.thresh.size();
 
-    if (s.lds_tables) {
-        const int lb = (int)s.lds_bytes;
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, JK_ILL_BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, JK_ILL_BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-        JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+    P.lds_seg_off = s.lds_seg_off;
+    {
+        const int lb = (int)s.lds_launch;
+        if (s.lds_tables) {
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, JK_ILL_BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, JK_ILL_BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        } else if (lb) {
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<false, 1, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<false, 2, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        }
     }
 }
 
@@ -433,7 +444,10 @@ static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min
     // ---- mutation tables -> device form (see HapDev)
     const uint64_t n_cells = nh * nc;
     std::vector<uint64_t> cell_off(n_cells + 1, 0);
-    for (uint64_t k = 0; k < n_cells; k++) cell_off[k + 1] = cell_off[k] + hs.n_mut[k];
+    for (uint64_t k = 0; k < n_cells; k++) {
+        if (hs.n_mut[k] > 0x7fffffffULL) throw Error(JK_ERR_UNSUPPORTED, "more than 2^31 mutations on one haplotype chromosome");
+        cell_off[k + 1] = cell_off[k] + hs.n_mut[k];
+    }
     const uint64_t n_mut = cell_off[n_cells];
     const uint64_t blob_len = n_mut ? hs.nuc_off[n_mut] : 0;
     upload_genome(s, hs.ref, hs.nuc_blob, blob_len);          // sets s.nuc_base = offset of the blob in seq
@@ -879,10 +893,10 @@ static void launch_generate(jk_session& s) {
         JK_HIP(hipEventRecord(s.events[ev++], s.stream));
 #define JK_LAUNCH(LDS, NE, HAP, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP>), dim3(grid), dim3(block), SH, s.stream, P)
         if (s.lds_tables) {
-            if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(true, 2, true, s.lds_bytes); else JK_LAUNCH(true, 1, true, s.lds_bytes); }
-            else       { if (s.n_ends == 2) JK_LAUNCH(true, 2, false, s.lds_bytes); else JK_LAUNCH(true, 1, false, s.lds_bytes); }
+            if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(true, 2, true, s.lds_launch); else JK_LAUNCH(true, 1, true, s.lds_launch); }
+            else       { if (s.n_ends == 2) JK_LAUNCH(true, 2, false, s.lds_launch); else JK_LAUNCH(true, 1, false, s.lds_launch); }
         } else {
-            if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(false, 2, true, 0); else JK_LAUNCH(false, 1, true, 0); }
+            if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(false, 2, true, s.lds_launch); else JK_LAUNCH(false, 1, true, s.lds_launch); }
             else       { if (s.n_ends == 2) JK_LAUNCH(false, 2, false, 0); else JK_LAUNCH(false, 1, false, 0); }
         }
 #undef JK_LAUNCH

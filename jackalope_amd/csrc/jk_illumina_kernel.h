@@ -98,6 +98,7 @@ struct IlluminaKernelParams {
     // info: [end][pos][nt] -> first entry (24 bits) | n entries (8 bits), 16 bytes per (end,pos)
     const uint32_t* info; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm_thresh;
     uint32_t n_info, n_entries;
+    uint32_t lds_seg_off;                                  // HAP: byte offset of the per-lane segment table in LDS
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -177,7 +178,8 @@ struct HapSeg { uint64_t addr, begin, end; };   // haplotype positions [begin, e
 
 // Which contiguous piece of the (encoded) buffer serves haplotype position hpos of `cell`?  `m` is the
 // cell-relative index of the last mutation with new_pos <= hpos (-1: none) and is updated in place.
-__device__ __forceinline__ HapSeg hap_resolve(const HapDev& H, uint64_t chrom_off, uint32_t cell, int64_t& m, uint64_t hpos) {
+template <typename MIdx>
+__device__ __forceinline__ HapSeg hap_resolve(const HapDev& H, uint64_t chrom_off, uint32_t cell, MIdx& m, uint64_t hpos) {
     const uint64_t mo = H.cell_mut_off[cell];
     const int64_t n = (int64_t)(H.cell_mut_off[cell + 1] - mo);
     while (m + 1 < n && H.new_pos[mo + m + 1] <= hpos) m++;
@@ -396,7 +398,9 @@ illumina_kernel(IlluminaKernelParams P) {
             // bytes are consumed low byte first from an 8-byte register chunk; for the reverse strand
             // the chunk is byte-swapped and complemented when it is loaded.
             const uint8_t* const gseq = P.g.seq;
-            const uint64_t chrom_off = P.g.chrom_off[HAP ? ci % P.g.n_chroms : ci];
+            // (HAP: the chromosome's offset is only needed when a segment is entered; it is re-read there
+            // instead of being carried through the per-base loop)
+            const uint64_t chrom_off = HAP ? 0 : P.g.chrom_off[ci];
             const uint8_t* const bcode = HAP ? P.h.bc_blob + (size_t)cur_hap * JK_MAX_BARCODE : P.barcode;
             uint64_t gaddr = 0;      // byte address (index into gseq) of the NEXT chunk to load
             uint64_t gbuf = 0; uint32_t gcnt = 0;
@@ -413,22 +417,56 @@ illumina_kernel(IlluminaKernelParams P) {
                 }
             };
             // HAP: the read is served segment by segment (reference runs and mutation bytes);
-            // seg_end_pp = first source position that is NOT in the current segment
+            // seg_end_pp = first source position that is NOT in the current segment.  The segments of the
+            // read's window are resolved ONCE here, before the per-base loop, into a small per-lane table in
+            // LDS (start position, buffer address; up to HAP_SEGS of them): a boundary met inside the loop then
+            // costs two LDS reads instead of a chain of dependent table loads from HBM -- with 64 lanes some
+            // lane meets a boundary in ~15 % of all iterations at 1.2 mutations per kb.  Reads that cross more
+            // segments than the table holds resolve the rest on the fly.
             uint32_t seg_end_pp = 0xffffffffu;
-            int64_t mcur = -1;
-            auto seg_enter = [&](uint32_t pp) {     // pp >= bc
-                const uint64_t hpos = reverse ? (start + sp - 1 - pp) : (start + pp - bc);
+            uint32_t seg_state = 0;                 // current segment | segments in the table << 8 | first unresolved position << 16
+            constexpr uint32_t HAP_SEGS = 4, NO_POS = 0xffffu;
+            uint32_t* const s_seg = HAP ? reinterpret_cast<uint32_t*>(smem + P.lds_seg_off) + threadIdx.x : nullptr;
+            auto seg_hpos = [&](uint32_t pp) -> uint64_t { return reverse ? (start + sp - 1 - pp) : (start + pp - bc); };
+            auto seg_enter = [&](uint32_t pp) {     // pp >= bc; pp is the first position of the next segment
                 if (HAP) {
-                    const HapSeg sg = hap_resolve(P.h, chrom_off, ci, mcur, hpos);
-                    src_init(sg.addr);
-                    const uint64_t avail = reverse ? (hpos - sg.begin + 1) : (sg.end - hpos);
-                    seg_end_pp = avail >= (uint64_t)(0xffffffffu - pp) ? 0xffffffffu : pp + (uint32_t)avail;
+                    const uint32_t cur = (seg_state & 0xffu) + 1u, n = (seg_state >> 8) & 0xffu, over = seg_state >> 16;
+                    if (cur < n) {
+                        const uint32_t* e = s_seg + 3u * cur * BLOCK;
+                        src_init(((uint64_t)e[2 * BLOCK] << 32) | e[BLOCK]);
+                        seg_end_pp = cur + 1u < n ? e[3 * BLOCK] : (over != NO_POS ? over : 0xffffffffu);
+                        seg_state = (seg_state & ~0xffu) | cur;
+                    } else {                        // beyond the table (rare): resolve from scratch
+                        const uint64_t hpos = seg_hpos(pp);
+                        int32_t m = (int32_t)hap_search(P.h, ci, hpos);
+                        const HapSeg sg = hap_resolve(P.h, P.g.chrom_off[ci % P.g.n_chroms], ci, m, hpos);
+                        src_init(sg.addr);
+                        const uint64_t avail = reverse ? (hpos - sg.begin + 1) : (sg.end - hpos);
+                        seg_end_pp = avail >= (uint64_t)(0xffffffffu - pp) ? 0xffffffffu : pp + (uint32_t)avail;
+                    }
                 } else {
-                    src_init(chrom_off + hpos);
+                    src_init(chrom_off + seg_hpos(pp));
                 }
             };
-            if (HAP) mcur = hap_search(P.h, ci, reverse ? (start + sp - 1 - bc) : start);
-            if (sp > bc) seg_enter(bc);
+            if (HAP) {
+                int32_t m = (int32_t)hap_search(P.h, ci, seg_hpos(bc));      // (a cell holds fewer than 2^31 mutations: checked at upload)
+                const uint64_t coff = P.g.chrom_off[ci % P.g.n_chroms];
+                uint32_t q = bc, n = 0;
+                while (q < sp && n < HAP_SEGS) {
+                    const uint64_t hpos = seg_hpos(q);
+                    const HapSeg sg = hap_resolve(P.h, coff, ci, m, hpos);
+                    uint32_t* e = s_seg + 3u * n * BLOCK;
+                    e[0] = q; e[BLOCK] = (uint32_t)sg.addr; e[2 * BLOCK] = (uint32_t)(sg.addr >> 32);
+                    n++;
+                    const uint64_t avail = reverse ? (hpos - sg.begin + 1) : (sg.end - hpos);
+                    q = avail >= (uint64_t)(sp - q) ? sp : q + (uint32_t)avail;
+                }
+                seg_state = (n << 8) | ((q < sp ? q : NO_POS) << 16);
+                if (n) {
+                    src_init(((uint64_t)s_seg[2 * BLOCK] << 32) | s_seg[BLOCK]);
+                    seg_end_pp = n > 1u ? s_seg[3 * BLOCK] : (q < sp ? q : 0xffffffffu);
+                }
+            } else if (sp > bc) seg_enter(bc);
             auto src_next = [&]() -> uint32_t {    // next base of the current segment
                 const uint32_t c = (uint32_t)gbuf & 0xffu;
                 gbuf >>= 8;

@@ -17,7 +17,7 @@ for h in range(n_haps):          # vectorised synthetic tables: substitutions 1e
     row = []
     for seq in ref.seqs:
         n = seq.size
-        k = int(n * 1.2e-3)
+        k = int(n * float(os.environ.get("JK_MUT_RATE", "1.2e-3")))
         pos = np.unique(rng.integers(1, n - 2, size=k) & ~np.int64(3))     # spaced >= 4 apart: never adjacent
         kind = rng.choice(3, size=pos.size, p=[1 / 1.2, 0.1 / 1.2, 0.1 / 1.2])
         delta = np.where(kind == 1, 1, np.where(kind == 2, -1, 0))
