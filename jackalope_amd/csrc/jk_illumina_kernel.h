@@ -632,7 +632,7 @@ __global__ void encode_bases_kernel(uint8_t* seq, uint64_t n, uint32_t* bad) {
 // each lane's 128 bytes are written by 8 consecutive threads as 16-byte pieces at the lane's final
 // offset (arbitrary alignment; unaligned dwordx4 stores are legal on gfx950 global memory).
 // ---------------------------------------------------------------------------------------------
-constexpr int CP_ROWS = 32;
+constexpr int CP_ROWS = 32;                     // words of every lane moved per step (128 bytes per lane; 64 and 128 measured slower)
 __global__ void __launch_bounds__(256)
 compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
                      const uint64_t* __restrict__ lane_bytes, const uint64_t* __restrict__ out_off,
@@ -648,8 +648,10 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
     const uint32_t max_bytes = s_max;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(pool + pool_off[tile]);
     const uint64_t base = out_base[0];
+    constexpr uint32_t PIECES = CP_ROWS / 4;                 // 16-byte pieces per lane and step
+    constexpr uint32_t LANES_PER_PASS = 256 / PIECES;
     for (uint32_t k0 = 0; k0 * 4u < max_bytes; k0 += CP_ROWS) {
-        // load CP_ROWS rows x 64 lanes (2048 words) coalesced
+        // load CP_ROWS rows x 64 lanes coalesced
 #pragma unroll
         for (uint32_t i = 0; i < (CP_ROWS * 64) / 256; i++) {
             const uint32_t idx = t + i * 256u, row = idx >> 6, l = idx & 63u;
@@ -658,10 +660,10 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
             tile_lds[row * 65u + l] = v;
         }
         __syncthreads();
-        // thread -> (lane, 16-byte piece): 8 consecutive threads cover one lane's 128 bytes
+        // thread -> (lane, 16-byte piece): PIECES consecutive threads cover one lane's bytes of this step
 #pragma unroll
-        for (uint32_t pass = 0; pass < 2; pass++) {
-            const uint32_t l = pass * 32u + (t >> 3), j = t & 7u;
+        for (uint32_t pass = 0; pass < 64 / LANES_PER_PASS; pass++) {
+            const uint32_t l = pass * LANES_PER_PASS + t / PIECES, j = t % PIECES;
             const uint32_t lane = lane0 + l;
             if (lane < n_lanes) {
                 const uint32_t nb = (uint32_t)lane_bytes[lane];
