@@ -85,6 +85,8 @@ struct jk_session {
     int device = 0;
     hipStream_t stream = nullptr;      // generator kernels
     hipStream_t cp_stream = nullptr;   // scan + compaction of the previous batch, overlapping the next one
+    hipStream_t stream2 = nullptr;     // Illumina: generator launches of odd batches (see launch_generate)
+    bool two_gen_streams = false;
     uint32_t n_ends = 1;
     bool paired = false;
     std::string out_prefix;
@@ -95,7 +97,7 @@ struct jk_session {
     IlluminaTables tables;
     DevBuf d_info, d_thresh, d_quals, d_mm;
     bool lds_tables = false;
-    size_t lds_bytes = 0, lds_launch = 0;
+    size_t lds_bytes = 0, lds_launch = 0, evw_set = 0;
     uint32_t lds_seg_off = 0;
     bool hap = false;
     int compress = 0;          // 0 = plain FASTQ, 1..9 = compression level
@@ -134,6 +136,7 @@ struct jk_session {
         for (hipEvent_t e : cp_done) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
         if (cp_stream) (void)hipStreamDestroy(cp_stream);
+        if (stream2) (void)hipStreamDestroy(stream2);
     }
 };
 
@@ -195,6 +198,8 @@ static void setup_model(jk_session& s, const jk_illumina_args& a) {
     JK_HIP(hipSetDevice(s.device));
     JK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     JK_HIP(hipStreamCreateWithFlags(&s.cp_stream, hipStreamNonBlocking));
+    JK_HIP(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
+    if (const char* e = std::getenv("JK_TWO_GEN_STREAMS")) s.two_gen_streams = std::atoi(e) != 0;
 
     s.tables = build_illumina_tables(a);
     const uint32_t L = s.tables.read_length;
@@ -331,7 +336,8 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     s.d_thresh.upload(s.tables.thresh);
     s.d_quals.upload(s.tables.quals);
     s.d_mm.upload(s.tables.mm_thresh);
-    s.d_evw.alloc((size_t)s.n_ends * 4 * s.ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
+    s.evw_set = (size_t)s.n_ends * 4 * s.ev_words * std::max<uint32_t>(max_lanes, 1);      // u64 words per generator in flight
+    s.d_evw.alloc(2 * s.evw_set * 8);
 
     s.lds_bytes = (s.tables.thresh.size() + (s.tables.thresh.size() & 1)) * 8 + 256 * 8 + s.tables.info.size() * 4 + align_up(s.tables.quals.size() * 2, 16);
     // haplotype runs add the per-lane segment table (4 segments x 12 bytes x 1024 lanes) after the tables
@@ -882,16 +888,21 @@ static void launch_generate(jk_session& s) {
             P.lane_bytes[e] = e < s.n_ends ? s.d_lane_bytes[e].as<uint64_t>() + B.lane0 : nullptr;
         }
         P.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
+        P.evw = s.d_evw.as<uint64_t>() + (size_t)pp * s.evw_set;
         P.chrom_stride = (uint32_t)s.n_shard;
+        // Two generators may be in flight (each has its own pool set and indel scratch): the next batch's
+        // workgroups then take over CUs as the current batch's finish instead of waiting for its slowest one.
+        hipStream_t gs = (s.two_gen_streams && (b & 1)) ? s.stream2 : s.stream;
+        if (s.two_gen_streams && b == 1) JK_HIP(hipStreamWaitEvent(s.stream2, s.events[0], 0));
 #ifndef JK_ILL_BLOCK
 #define JK_ILL_BLOCK 1024
 #endif
         const uint32_t block = JK_ILL_BLOCK;
         const uint32_t grid = (B.n_lanes + block - 1) / block;
         // the pool set is free again once the compaction of batch b-2 has read it
-        if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));
-        JK_HIP(hipEventRecord(s.events[ev++], s.stream));
-#define JK_LAUNCH(LDS, NE, HAP, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP>), dim3(grid), dim3(block), SH, s.stream, P)
+        if (b >= 2) JK_HIP(hipStreamWaitEvent(gs, s.cp_done[b - 2], 0));
+        JK_HIP(hipEventRecord(s.events[ev++], gs));
+#define JK_LAUNCH(LDS, NE, HAP, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP>), dim3(grid), dim3(block), SH, gs, P)
         if (s.lds_tables) {
             if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(true, 2, true, s.lds_launch); else JK_LAUNCH(true, 1, true, s.lds_launch); }
             else       { if (s.n_ends == 2) JK_LAUNCH(true, 2, false, s.lds_launch); else JK_LAUNCH(true, 1, false, s.lds_launch); }
@@ -901,8 +912,8 @@ static void launch_generate(jk_session& s) {
         }
 #undef JK_LAUNCH
         JK_HIP(hipGetLastError());
-        JK_HIP(hipEventRecord(s.events[ev++], s.stream));
-        JK_HIP(hipEventRecord(s.gen_done[b], s.stream));
+        JK_HIP(hipEventRecord(s.events[ev++], gs));
+        JK_HIP(hipEventRecord(s.gen_done[b], gs));
         JK_HIP(hipStreamWaitEvent(s.cp_stream, s.gen_done[b], 0));
         const uint32_t nb = (B.n_lanes + SCAN_BLOCK - 1) / SCAN_BLOCK;
         for (uint32_t e = 0; e < s.n_ends; e++) {
