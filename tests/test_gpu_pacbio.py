@@ -108,3 +108,32 @@ def test_lane_shards_and_files(ja, O, tmp_path):
     prefix = str(tmp_path / "pb")
     ja.pacbio(g, prefix, n, n_threads=T, seed_words=words)
     assert open(prefix + "_R1.fq", "rb").read() == whole
+
+
+def test_sep_files_and_compressed_sink(ja, O, tmp_path):
+    """write_reads_cpp_sep_files_ (src/hts.h:512-552) on the PacBio path: one reads_per_group draw splits the reads
+    over haplotypes, then one run per haplotype with one-hot probabilities -> <prefix>_<hap>_R1.fq[.gz]."""
+    import ctypes as C
+    import gzip
+    ref = ja.synthetic_genome([120_000, 30_000], seed=61)
+    hs = random_haplotypes(ref, 3, seed=62, sub_rate=0.01, ins_rate=0.002, del_rate=0.002)
+    T, n = 5, 240
+    words = ja.seed_words(11, hs.seed_budget(T))
+    pb = {"custom_read_lengths": [400, 1500, 3000]}
+    prefix = str(tmp_path / "pbsep")
+    ja.pacbio(hs, prefix, n, n_threads=T, seed_words=words, sep_files=True, haplotype_probs=[2, 1, 1], compress=True, **pb)
+    probs = np.array([2.0, 1.0, 1.0])
+    per_file, used = np.zeros(3, dtype=np.uint64), C.c_uint64()
+    assert O.lib().orc_reads_per_group(C.c_uint64(n), probs.ctypes.data_as(C.c_void_p), C.c_uint64(3),
+                                       words.ctypes.data_as(C.c_void_p), C.c_uint64(words.size),
+                                       per_file.ctypes.data_as(C.c_void_p), C.byref(used)) == 0
+    pos, total = int(used.value), 0
+    for h in range(3):
+        one_hot = [1.0 if k == h else 0.0 for k in range(3)]
+        o, u, _ = O.pacbio_hap(hs, pb, hap_probs=one_hot, n_reads=int(per_file[h]), n_threads=T, words=words[pos:])
+        pos += u
+        raw = open("%s_hap%d_R1.fq.gz" % (prefix, h), "rb").read()
+        assert gzip.decompress(raw) == o
+        assert raw[12:14] == b"BC"                 # BGZF blocks (made on the device)
+        total += len(fastq_records(o))
+    assert total == n
