@@ -416,7 +416,8 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
     std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
     std::vector<uint64_t> lane_reads(s.n_shard);
     std::vector<uint32_t> chrom_reads((size_t)s.n_chroms * s.n_shard, 0);
-    std::vector<double> chrom_probs(g.chrom_lens, g.chrom_lens + g.n_chroms);
+    const std::vector<std::vector<double>> chrom_probs(1, std::vector<double>(g.chrom_lens, g.chrom_lens + g.n_chroms));
+    DeferredSplits splits(&chrom_probs, chrom_reads.data(), s.n_shard, s.paired ? 2u : 1u);
     for (uint64_t t = 0; t < T; t++) {
         // IlluminaOneGenome::add_n_reads (src/hts_illumina.h:410-418)
         uint64_t n = per_lane[t];
@@ -428,12 +429,9 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
         }
         const uint64_t l = t - s.lane_begin;
         lane_reads[l] = per_lane[t];
-        std::vector<uint64_t> cr = reads_per_group(n, chrom_probs, seeds);
-        for (uint32_t c = 0; c < s.n_chroms; c++) {
-            uint64_t v = cr[c] * (s.paired ? 2 : 1);
-            chrom_reads[(size_t)c * s.n_shard + l] = (uint32_t)v;
-        }
+        splits.add(n, seeds, 0, 0, l);
     }
+    splits.flush();
     s.seed_words_used = seeds.pos;
 
     IlluminaKernelParams& P = s.kp;
@@ -566,17 +564,15 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
     std::vector<uint32_t> vc((size_t)n_cells * s.n_shard, 0);
     std::vector<std::vector<double>> chrom_probs(nh, std::vector<double>(nc));
     for (uint64_t h = 0; h < nh; h++) for (uint64_t c = 0; c < nc; c++) chrom_probs[h][c] = (double)cell_size[h * nc + c];
+    DeferredSplits splits(&chrom_probs, vc.data(), s.n_shard, s.paired ? 2u : 1u);
     for (uint64_t t = 0; t < T; t++) {
         uint64_t n = per_lane[t];
         if (s.paired) n /= 2;
         const bool mine = t >= s.lane_begin && t < s.lane_end;
         std::vector<uint64_t> hap_reads = reads_per_group(n, hap_probs, seeds);
         for (uint64_t h = 0; h < nh; h++) {
-            if (mine) {
-                std::vector<uint64_t> cr = reads_per_group(hap_reads[h], chrom_probs[h], seeds);
-                for (uint64_t c = 0; c < nc; c++)
-                    vc[(size_t)(h * nc + c) * s.n_shard + (t - s.lane_begin)] = (uint32_t)(cr[c] * (s.paired ? 2 : 1));
-            } else if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }
+            if (mine) splits.add(hap_reads[h], seeds, (uint32_t)h, h * nc, t - s.lane_begin);
+            else if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }
         }
         for (uint64_t h = 0; h < nh; h++) {
             uint64_t m = hap_reads[h];
@@ -585,6 +581,7 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
         }
         if (mine) lane_reads[t - s.lane_begin] = per_lane[t];
     }
+    splits.flush();
     s.seed_words_used = seeds.pos;
 
     IlluminaKernelParams& P = s.kp;
@@ -763,16 +760,17 @@ static void open_pacbio_ref(jk_session& s, const jk_ref_genome& g, const jk_pacb
     std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
     std::vector<uint64_t> lane_reads(s.n_shard);
     std::vector<uint32_t> chrom_reads((size_t)s.n_chroms * s.n_shard, 0);
-    std::vector<double> chrom_probs(g.chrom_lens, g.chrom_lens + g.n_chroms);
+    const std::vector<std::vector<double>> chrom_probs(1, std::vector<double>(g.chrom_lens, g.chrom_lens + g.n_chroms));
+    DeferredSplits splits(&chrom_probs, chrom_reads.data(), s.n_shard, 1u);
     for (uint64_t t = 0; t < T; t++) {
         const uint64_t n = per_lane[t];
         const bool mine = t >= s.lane_begin && t < s.lane_end;
         if (!mine) { if (n > 0) { uint32_t w[8]; seeds.take8(w); } continue; }
         const uint64_t l = t - s.lane_begin;
         lane_reads[l] = n;
-        std::vector<uint64_t> cr = reads_per_group(n, chrom_probs, seeds);
-        for (uint32_t c = 0; c < s.n_chroms; c++) chrom_reads[(size_t)c * s.n_shard + l] = (uint32_t)cr[c];
+        splits.add(n, seeds, 0, 0, l);
     }
+    splits.flush();
     s.seed_words_used = seeds.pos;
     const uint64_t mbb = a.max_batch_bytes;
     jk_session* sp = &s;
@@ -810,19 +808,19 @@ static void open_pacbio_hap(jk_session& s, const jk_hap_set& hs, const jk_pacbio
     std::vector<uint32_t> vc((size_t)n_cells * s.n_shard, 0);
     std::vector<std::vector<double>> chrom_probs(nh, std::vector<double>(nc));
     for (uint64_t h = 0; h < nh; h++) for (uint64_t c = 0; c < nc; c++) chrom_probs[h][c] = (double)cell_size[h * nc + c];
+    DeferredSplits splits(&chrom_probs, vc.data(), s.n_shard, 1u);
     for (uint64_t t = 0; t < T; t++) {
         const uint64_t n = per_lane[t];
         const bool mine = t >= s.lane_begin && t < s.lane_end;
         std::vector<uint64_t> hap_reads = reads_per_group(n, hap_probs, seeds);
         for (uint64_t h = 0; h < nh; h++) {
-            if (mine) {
-                std::vector<uint64_t> cr = reads_per_group(hap_reads[h], chrom_probs[h], seeds);
-                for (uint64_t c = 0; c < nc; c++) vc[(size_t)(h * nc + c) * s.n_shard + (t - s.lane_begin)] = (uint32_t)cr[c];
-            } else if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }
+            if (mine) splits.add(hap_reads[h], seeds, (uint32_t)h, h * nc, t - s.lane_begin);
+            else if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }
         }
         for (uint64_t h = 0; h < nh; h++) if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }   // read_makers[h].add_n_reads
         if (mine) lane_reads[t - s.lane_begin] = n;
     }
+    splits.flush();
     s.seed_words_used = seeds.pos;
     set_hap_params(s, s.kpb.h, (uint32_t)nh);
     const uint64_t mbb = a.max_batch_bytes;

@@ -17,6 +17,7 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/jackalope_hip.h"
@@ -81,14 +82,11 @@ inline std::vector<uint64_t> split_int(uint64_t x, uint64_t n) {
     return out;
 }
 
-// Sequential conditional binomials over groups (reference: src/hts.h:58-103).  Consumes 8 seed words
-// whenever n_reads > 0 and there is at least one group, even when no binomial is then drawn.
-inline std::vector<uint64_t> reads_per_group(uint64_t n_reads, std::vector<double> probs, SeedReader& seeds) {
+// Sequential conditional binomials over groups (reference: src/hts.h:58-103) from a fresh engine seeded
+// with the 8 words `w`.
+inline std::vector<uint64_t> reads_per_group_w(uint64_t n_reads, std::vector<double> probs, const uint32_t* w) {
     const size_t G = probs.size();
     std::vector<uint64_t> out(G, 0);
-    if (n_reads == 0 || G == 0) return out;
-    uint32_t w[8];
-    seeds.take8(w);
     HostPcg eng{jk_pcg_seed(w)};
     double total = std::accumulate(probs.begin(), probs.end(), 0.0);
     for (double& p : probs) p /= total;
@@ -106,10 +104,54 @@ inline std::vector<uint64_t> reads_per_group(uint64_t n_reads, std::vector<doubl
     out[G - 1] = n_reads;
     return out;
 }
+// ... taking the words itself.  Consumes 8 seed words whenever n_reads > 0 and there is at least one
+// group, even when no binomial is then drawn.
+inline std::vector<uint64_t> reads_per_group(uint64_t n_reads, const std::vector<double>& probs, SeedReader& seeds) {
+    if (n_reads == 0 || probs.empty()) return std::vector<uint64_t>(probs.size(), 0);
+    uint32_t w[8];
+    seeds.take8(w);
+    return reads_per_group_w(n_reads, probs, w);
+}
 
-// ---- alias tables -----------------------------------------------------------------------------
-// Vose's method with FIFO small/large queues, normalisation p /= accu(p); p *= n where accu is
-// Armadillo's two-accumulator sum (the reference links RcppArmadillo; src/alias_sampler.h:70-71).
+// The per-lane chromosome splits of a run with ~10^6 lanes are ~10^8 binomial draws; one reference thread
+// does its own, here one host would do them all.  The seed words are still taken in the reference's order
+// on the calling thread (R's RNG is sequential); the binomial chains, which only depend on their 8 words,
+// run on host threads.  out[(cell0 + c) * stride + lane] = reads of group c, times `mult`.
+struct DeferredSplits {
+    struct Task { uint64_t n; uint32_t w[8]; uint32_t probs_id; uint64_t cell0, lane; };
+    const std::vector<std::vector<double>>* probs;
+    uint32_t* out; size_t stride; uint32_t mult;
+    std::vector<Task> tasks;
+    DeferredSplits(const std::vector<std::vector<double>>* p, uint32_t* o, size_t st, uint32_t m) : probs(p), out(o), stride(st), mult(m) {}
+    void add(uint64_t n, SeedReader& seeds, uint32_t probs_id, uint64_t cell0, uint64_t lane) {
+        if (n == 0 || (*probs)[probs_id].empty()) return;        // reads_per_group: nothing drawn, nothing consumed
+        Task t; t.n = n; t.probs_id = probs_id; t.cell0 = cell0; t.lane = lane;
+        seeds.take8(t.w);
+        tasks.push_back(t);
+        if (tasks.size() >= (1u << 16)) flush();
+    }
+    void flush() {
+        const size_t n = tasks.size();
+        if (n == 0) return;
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t n_thr = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)32, n / 256 + 1}));
+        auto work = [&](size_t a, size_t b) {
+            for (size_t i = a; i < b; i++) {
+                const Task& t = tasks[i];
+                const std::vector<uint64_t> cr = reads_per_group_w(t.n, (*probs)[t.probs_id], t.w);
+                for (size_t c = 0; c < cr.size(); c++) out[(t.cell0 + c) * stride + t.lane] = (uint32_t)(cr[c] * mult);
+            }
+        };
+        if (n_thr == 1) work(0, n);
+        else {
+            std::vector<std::thread> pool;
+            for (size_t k = 0; k < n_thr; k++) pool.emplace_back(work, n * k / n_thr, n * (k + 1) / n_thr);
+            for (std::thread& th : pool) th.join();
+        }
+        tasks.clear();
+    }
+};
+
 struct AliasTable {
     std::vector<double> prob;
     std::vector<uint64_t> alias;

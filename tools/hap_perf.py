@@ -8,7 +8,7 @@ from jackalope_amd.genome import HapSet
 mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 400.0
 n_haps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 20
-nc = 4
+nc = int(os.environ.get("JK_NCHROM", "4"))
 ref = ja.synthetic_genome([int(mbp * 1e6 / nc)] * nc, seed=3)
 rng = np.random.default_rng(31)
 cells = []
