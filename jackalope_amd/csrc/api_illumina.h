@@ -1,0 +1,456 @@
+// api_illumina.h -- host set-up of the Illumina sessions: genome upload, error model tables, lanes, pools
+// (part of the one translation unit jk_api.hip; see the include list there)
+#pragma once
+
+namespace jk {
+
+// Chromosomes (+ optionally the haplotypes' nucleotide blob) into one encoded device buffer.
+static void upload_genome(jk_session& s, const jk_ref_genome& g, const char* blob_bytes, uint64_t blob_len) {
+    if (g.n_chroms == 0) throw Error(JK_ERR_ARG, "reference genome has no chromosomes");
+    if (g.n_chroms > 0xffffffffULL) throw Error(JK_ERR_UNSUPPORTED, "too many chromosomes");
+    std::vector<uint64_t> off(g.n_chroms), len(g.n_chroms);
+    uint64_t total = 64;
+    for (uint64_t i = 0; i < g.n_chroms; i++) { off[i] = total; len[i] = g.chrom_lens[i]; total = align_up(total + len[i], 64) + 64; }
+    s.nuc_base = total;
+    total = align_up(total + blob_len, 64) + 64;
+    s.d_seq.alloc(total);
+    JK_HIP(hipMemset(s.d_seq.p, 'N', total));
+    if (blob_len) JK_HIP(hipMemcpy(s.d_seq.as<uint8_t>() + s.nuc_base, blob_bytes, blob_len, hipMemcpyHostToDevice));
+    for (uint64_t i = 0; i < g.n_chroms; i++)
+        if (len[i]) JK_HIP(hipMemcpy(s.d_seq.as<uint8_t>() + off[i], g.chrom_seqs[i], len[i],
+                                     g.seqs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    // T,C,A,G -> 0..3, everything else -> 4 (what nt_map / cmp_map of the reference distinguish)
+    DevBuf bad; bad.alloc(4);
+    JK_HIP(hipMemset(bad.p, 0, 4));
+    hipLaunchKernelGGL(encode_bases_kernel, dim3(2048), dim3(256), 0, 0, s.d_seq.as<uint8_t>(), total, bad.as<uint32_t>());
+    JK_HIP(hipGetLastError());
+    JK_HIP(hipDeviceSynchronize());
+    uint32_t bad_h = 0;
+    JK_HIP(hipMemcpy(&bad_h, bad.p, 4, hipMemcpyDeviceToHost));
+    if (bad_h) throw Error(JK_ERR_UNSUPPORTED, "the genome contains bytes 0xfc-0xff, which the GPU path cannot represent");
+    s.d_chrom_off.upload(off);
+    s.d_chrom_len.upload(len);
+    s.n_chroms = (uint32_t)g.n_chroms;
+}
+
+// compress / comp_method of the reference's entry points (write_reads_cpp_, src/hts.h:453-496)
+static void set_compression(jk_session& s, int compress, const char* comp_method) {
+    if (compress < 0 || compress > 9) throw Error(JK_ERR_ARG, "\nInvalid bgzip compress level of " + std::to_string(compress) + ". It must be in range [0,9].");
+    s.compress = compress;
+    const std::string m = comp_method ? comp_method : "bgzip";
+    if (compress > 0 && m != "gzip" && m != "bgzip" && m != "bgzip-host") throw Error(JK_ERR_ARG, "\nUnrecognized compression method.");
+    s.bgzip = (m != "gzip");
+    s.host_deflate = (m == "bgzip-host");
+}
+
+static inline uint8_t encode_base(char c) { return c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : 4; }
+
+// ---- pieces shared by the reference-genome and haplotype entry points --------------------------
+
+// Argument checks + error-model tables + every per-run constant of the kernel.
+static void setup_model(jk_session& s, const jk_illumina_args& a) {
+    set_compression(s, a.compress, a.comp_method);
+    if (a.frag_len_shape < 1.0) throw Error(JK_ERR_UNSUPPORTED, "frag_len_shape < 1 (fragment sd > mean) is not implemented on the GPU path");
+    if (!(a.frag_len_scale > 0)) throw Error(JK_ERR_ARG, "frag_len_scale must be > 0");
+    s.paired = a.paired != 0;
+    s.n_ends = s.paired ? 2 : 1;
+    s.out_prefix = a.out_prefix ? a.out_prefix : "";
+    s.abort_flag = a.abort_flag;
+    s.device = a.device;
+    JK_HIP(hipSetDevice(s.device));
+    JK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    JK_HIP(hipStreamCreateWithFlags(&s.cp_stream, hipStreamNonBlocking));
+    JK_HIP(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
+    if (const char* e = std::getenv("JK_TWO_GEN_STREAMS")) s.two_gen_streams = std::atoi(e) != 0;
+
+    s.tables = build_illumina_tables(a);
+    const uint32_t L = s.tables.read_length;
+    s.ev_words = (2 * L + 63) / 64 + 1;
+    if (s.ev_words > (uint32_t)JK_MAX_EVW) throw Error(JK_ERR_UNSUPPORTED, "read lengths above 480 are not implemented on the GPU path");
+
+    IlluminaKernelParams& P = s.kp;
+    P.read_len = L; P.n_ends = s.n_ends; P.paired = s.paired; P.matepair = (s.paired && a.matepair) ? 1 : 0;
+    P.ev_words = s.ev_words;
+    P.frag_min = a.frag_len_min; P.frag_max = a.frag_len_max;
+    {   // gamma_distribution<double>::param_type::_M_initialize (random.tcc:2330-2346), alpha >= 1
+        const double a1 = a.frag_len_shape - 1.0 / 3.0;
+        P.gp.a1 = a1;
+        P.gp.a2 = 1.0 / std::sqrt(9.0 * a1);
+        P.gp.beta = a.frag_len_scale;
+    }
+    const double insp[2] = {a.ins_prob1, a.ins_prob2}, delp[2] = {a.del_prob1, a.del_prob2};
+    for (uint32_t r = 0; r < 2; r++) {
+        // u > (ins + del) -> match ; else u > ins -> deletion ; else insertion (hts_illumina.cpp:133-144)
+        Threshold tm = threshold_le(insp[r] + delp[r]);
+        Threshold td = threshold_le(insp[r]);
+        P.th_match[r] = tm.th; P.never_match[r] = tm.all;
+        P.th_del[r] = td.th; P.never_del[r] = td.all;
+    }
+    {   // dup < prob_dup (src/hts.h:265-266)
+        Threshold t = threshold_lt(a.prob_dup);
+        P.th_dup = t.th; P.dup_all = t.all;
+    }
+    P.pool_size = a.read_pool_size;
+}
+
+static void check_barcode(const std::string& bc, uint32_t L) {
+    if (bc.size() > (size_t)JK_MAX_BARCODE) throw Error(JK_ERR_UNSUPPORTED, "barcodes longer than 32 bases are not implemented on the GPU path");
+    if (bc.size() >= L) throw Error(JK_ERR_ARG, "barcode must be shorter than the read length");
+}
+
+// Lanes of the run and of this process's shard; per-lane read quotas (src/hts.h:334-336).
+static std::vector<uint64_t> plan_lanes(jk_session& s, uint64_t n_threads, uint64_t lane_begin, uint64_t lane_end, uint64_t n_reads) {
+    uint64_t T = n_threads ? n_threads : 1;
+    s.n_lanes_total = T;
+    s.lane_begin = lane_begin;
+    s.lane_end = lane_end ? lane_end : T;
+    if (s.lane_begin > s.lane_end || s.lane_end > T) throw Error(JK_ERR_ARG, "lane shard out of range");
+    s.n_shard = s.lane_end - s.lane_begin;
+    std::vector<uint64_t> per_lane = split_int(n_reads / s.n_ends, T);
+    for (uint64_t& v : per_lane) v *= s.n_ends;
+    if (per_lane[0] > 0xffffffffULL) throw Error(JK_ERR_UNSUPPORTED, "more than 2^32 reads per lane: raise n_threads");
+    return per_lane;
+}
+
+// mt_seeds (src/pcg.h:37-46): 8 words per lane for ALL lanes, in lane order; keep this shard's.
+static std::vector<uint32_t> take_lane_seeds(jk_session& s, SeedReader& seeds) {
+    std::vector<uint32_t> lane_seeds(s.n_shard * 8);
+    uint32_t w[8];
+    for (uint64_t t = 0; t < s.n_lanes_total; t++) {
+        seeds.take8(w);
+        if (t >= s.lane_begin && t < s.lane_end) std::memcpy(&lane_seeds[(t - s.lane_begin) * 8], w, sizeof(w));
+    }
+    return lane_seeds;
+}
+
+// Pools: tiles of 64 lanes (one wave), every lane of a tile gets the capacity of the tile's largest
+// quota of maximal records; a batch is a run of whole tiles.  Then all device buffers.
+// lane_cap[l] = pool bytes lane l may need.  Plans batches/tiles and allocates everything that does not
+// depend on the sequencer model.  Returns the largest number of lanes in a batch.
+static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint64_t lanes_per_batch,
+                                  const std::vector<uint64_t>& lane_cap, const std::vector<uint64_t>& lane_reads,
+                                  const std::vector<uint32_t>& lane_seeds, const std::vector<uint32_t>& quotas) {
+    s.batches.clear(); s.batch_pool_off_index.clear();
+    const uint64_t max_batch = max_batch_bytes ? max_batch_bytes : (8ULL << 30);
+    uint64_t max_batch_lanes = lanes_per_batch;
+    if (const char* e = std::getenv("JK_BATCH_LANES")) { const long long v = std::atoll(e); if (v >= 64) max_batch_lanes = (uint64_t)v / 64 * 64; }
+    std::vector<uint64_t> pool_off;
+    uint64_t out_cap = 0, max_pool = 0;
+    uint32_t max_lanes = 0;
+    uint64_t l = 0;
+    while (l < s.n_shard) {
+        Batch b{l, 0, 0};
+        s.batch_pool_off_index.push_back(pool_off.size());
+        pool_off.push_back(0);
+        uint64_t used = 0;
+        while (l < s.n_shard && b.n_lanes < max_batch_lanes) {
+            const uint64_t tl = std::min<uint64_t>(64, s.n_shard - l);
+            uint64_t mx = 0;
+            for (uint64_t k = 0; k < tl; k++) mx = std::max(mx, lane_cap[l + k]);
+            const uint64_t cap = align_up(mx, 4) * 64;
+            if (b.n_lanes > 0 && used + cap > max_batch) break;
+            used += cap; pool_off.push_back(used); b.n_lanes += (uint32_t)tl; l += tl;
+        }
+        b.pool_bytes = used;
+        out_cap += used;
+        max_pool = std::max(max_pool, used);
+        max_lanes = std::max(max_lanes, b.n_lanes);
+        s.batches.push_back(b);
+    }
+    s.out_cap = out_cap;
+    s.d_seeds.upload(lane_seeds);
+    s.d_lane_reads.upload(lane_reads);
+    s.d_chrom_reads.upload(quotas);
+    s.d_pool_off.upload(pool_off);
+    for (uint32_t e = 0; e < s.n_ends; e++) {
+        s.d_pool[0][e].alloc(max_pool + 64);
+        if (s.batches.size() > 1) s.d_pool[1][e].alloc(max_pool + 64);
+        s.d_out[e].alloc(out_cap + 64);
+        s.d_lane_bytes[e].alloc(s.n_shard * 8);
+        s.d_lane_off[e].alloc(s.n_shard * 8);
+        s.d_base[e].alloc((s.batches.size() + 1) * 8);
+    }
+    s.d_lane_made.alloc(s.n_shard * 8);
+    s.d_block_sums.alloc((max_lanes / SCAN_BLOCK + 2) * 8);
+    s.d_err.alloc(4);
+    for (hipEvent_t e : s.events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s.gen_done) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s.cp_done) (void)hipEventDestroy(e);
+    s.events.assign(2 + 2 * s.batches.size() + 2, nullptr);
+    for (hipEvent_t& e : s.events) JK_HIP(hipEventCreate(&e));
+    s.gen_done.assign(s.batches.size(), nullptr);
+    s.cp_done.assign(s.batches.size(), nullptr);
+    for (hipEvent_t& e : s.gen_done) JK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : s.cp_done) JK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return max_lanes;
+}
+
+static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const std::vector<uint64_t>& lane_reads,
+                                 uint64_t rec_max, const std::vector<uint32_t>& lane_seeds,
+                                 const std::vector<uint32_t>& quotas) {
+    // A batch is one generator launch.  Default: 2^18 lanes = one 1024-thread workgroup on each of the
+    // 256 CUs, so every launch is a single full wave of workgroups and the pool compaction of batch b
+    // (HBM-bound, second stream) runs under the generator of batch b+1 (ALU-bound).
+    std::vector<uint64_t> lane_cap(s.n_shard);
+    for (uint64_t l = 0; l < s.n_shard; l++) lane_cap[l] = (lane_reads[l] / s.n_ends) * rec_max;
+    const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, 1ULL << 18, lane_cap, lane_reads, lane_seeds, quotas);
+    s.d_info.upload(s.tables.info);
+    s.d_thresh.upload(s.tables.thresh);
+    s.d_quals.upload(s.tables.quals);
+    s.d_mm.upload(s.tables.mm_thresh);
+    s.evw_set = (size_t)s.n_ends * 4 * s.ev_words * std::max<uint32_t>(max_lanes, 1);      // u64 words per generator in flight
+    s.d_evw.alloc(2 * s.evw_set * 8);
+
+    s.lds_bytes = (s.tables.thresh.size() + (s.tables.thresh.size() & 1)) * 8 + 256 * 8 + s.tables.info.size() * 4 + align_up(s.tables.quals.size() * 2, 16);
+    // haplotype runs add the per-lane segment table (4 segments x 12 bytes x 1024 lanes) after the tables
+    const size_t seg_bytes = s.hap ? (size_t)4 * 12 * JK_ILL_BLOCK : 0;
+    s.lds_tables = s.lds_bytes + seg_bytes <= 158 * 1024;
+    s.lds_seg_off = s.lds_tables ? (uint32_t)align_up(s.lds_bytes, 16) : 0;
+    s.lds_launch = (s.lds_tables ? align_up(s.lds_bytes, 16) : 0) + seg_bytes;
+
+    IlluminaKernelParams& P = s.kp;
+    P.g.seq = s.d_seq.as<uint8_t>();
+    P.g.chrom_off = s.d_chrom_off.as<uint64_t>();
+    P.g.chrom_len = s.d_chrom_len.as<uint64_t>();
+    P.g.hdr_blob = s.d_hdr_blob.as<uint8_t>();
+    P.g.hdr_off = s.d_hdr_off.as<uint32_t>();
+    P.g.n_chroms = s.n_chroms;
+    P.evw = s.d_evw.as<uint64_t>();
+    P.err = s.d_err.as<uint32_t>();
+    P.info = s.d_info.as<uint32_t>(); P.thresh = s.d_thresh.as<uint64_t>();
+    P.quals = s.d_quals.as<uint16_t>(); P.mm_thresh = s.d_mm.as<uint64_t>();
+    P.n_info = (uint32_t)s.tables.info.size(); P.n_entries = (uint32_t)s.tables.thresh.size();
+
+    P.lds_seg_off = s.lds_seg_off;
+    {
+        const int lb = (int)s.lds_launch;
+        if (s.lds_tables) {
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, JK_ILL_BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, JK_ILL_BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        } else if (lb) {
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<false, 1, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<false, 2, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+        }
+    }
+}
+
+static uint64_t record_max(size_t max_hdr, uint64_t max_chrom, bool paired, uint32_t L) {
+    return max_hdr + n_digits(max_chrom) + 2 + (paired ? 2 : 0) + 1 + (uint64_t)L + 3 + L + 1;
+}
+
+// ---- illumina_ref_cpp (src/hts_illumina.cpp:589-649): everything the reference does on the calling
+// thread before the parallel region, plus device set-up.
+static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_illumina_args& a, SeedReader& seeds) {
+    setup_model(s, a);
+    const uint32_t L = s.tables.read_length;
+    const std::string barcode = (a.barcodes && a.n_barcodes > 0 && a.barcodes[0]) ? a.barcodes[0] : "";
+    check_barcode(barcode, L);
+    upload_genome(s, g, nullptr, 0);
+    uint64_t min_chrom = ~0ULL, max_chrom = 0;
+    size_t max_hdr = 0;
+    const std::string gname = g.name ? g.name : "REF";
+    for (uint64_t i = 0; i < g.n_chroms; i++) {
+        min_chrom = std::min<uint64_t>(min_chrom, g.chrom_lens[i]);
+        max_chrom = std::max<uint64_t>(max_chrom, g.chrom_lens[i]);
+        max_hdr = std::max(max_hdr, 3 + gname.size() + std::strlen(g.chrom_names ? g.chrom_names[i] : ""));
+    }
+    {
+        std::vector<uint8_t> blob;
+        std::vector<uint32_t> hoff(g.n_chroms + 1);
+        for (uint64_t i = 0; i < g.n_chroms; i++) {
+            hoff[i] = (uint32_t)blob.size();
+            std::string h = "@" + gname + "-" + (g.chrom_names ? g.chrom_names[i] : "") + "-";
+            blob.insert(blob.end(), h.begin(), h.end());
+        }
+        hoff[g.n_chroms] = (uint32_t)blob.size();
+        s.d_hdr_blob.upload(blob);
+        s.d_hdr_off.upload(hoff);
+    }
+    const uint64_t frag_lb = std::min<uint64_t>(a.frag_len_min <= a.frag_len_max ? a.frag_len_min : a.frag_len_max, min_chrom);
+    if (frag_lb < std::max<uint64_t>(barcode.size(), 1))
+        throw Error(JK_ERR_UNSUPPORTED, "fragments shorter than the barcode (or empty) are not implemented on the GPU path");
+
+    // ---- lanes, quotas, seeds: same order of seed consumption as src/hts.h:334-353
+    std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, a.n_reads);
+    const uint64_t T = s.n_lanes_total;
+    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
+    std::vector<uint64_t> lane_reads(s.n_shard);
+    std::vector<uint32_t> chrom_reads((size_t)s.n_chroms * s.n_shard, 0);
+    const std::vector<std::vector<double>> chrom_probs(1, std::vector<double>(g.chrom_lens, g.chrom_lens + g.n_chroms));
+    DeferredSplits splits(&chrom_probs, chrom_reads.data(), s.n_shard, s.paired ? 2u : 1u);
+    for (uint64_t t = 0; t < T; t++) {
+        // IlluminaOneGenome::add_n_reads (src/hts_illumina.h:410-418)
+        uint64_t n = per_lane[t];
+        if (s.paired) n /= 2;
+        const bool mine = t >= s.lane_begin && t < s.lane_end;
+        if (!mine) {                       // only keep the seed stream in step
+            if (n > 0) { uint32_t w[8]; seeds.take8(w); }
+            continue;
+        }
+        const uint64_t l = t - s.lane_begin;
+        lane_reads[l] = per_lane[t];
+        splits.add(n, seeds, 0, 0, l);
+    }
+    splits.flush();
+    s.seed_words_used = seeds.pos;
+
+    IlluminaKernelParams& P = s.kp;
+    P.bc_len = (uint32_t)barcode.size();
+    std::memset(P.barcode, 0, sizeof(P.barcode));
+    for (size_t k = 0; k < barcode.size(); k++) P.barcode[k] = encode_base(barcode[k]);
+    plan_pools_and_alloc(s, a, lane_reads, record_max(max_hdr, max_chrom, s.paired, L), lane_seeds, chrom_reads);
+}
+
+// Mutation tables of a haplotype set -> device form (see HapDev); also uploads the genome + nucleotide blob.
+static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min_chrom, uint64_t& max_chrom,
+                              std::vector<uint64_t>& cell_size) {
+    const uint64_t nh = hs.n_haps, nc = hs.ref.n_chroms;
+    // ---- mutation tables -> device form (see HapDev)
+    const uint64_t n_cells = nh * nc;
+    std::vector<uint64_t> cell_off(n_cells + 1, 0);
+    for (uint64_t k = 0; k < n_cells; k++) {
+        if (hs.n_mut[k] > 0x7fffffffULL) throw Error(JK_ERR_UNSUPPORTED, "more than 2^31 mutations on one haplotype chromosome");
+        cell_off[k + 1] = cell_off[k] + hs.n_mut[k];
+    }
+    const uint64_t n_mut = cell_off[n_cells];
+    const uint64_t blob_len = n_mut ? hs.nuc_off[n_mut] : 0;
+    upload_genome(s, hs.ref, hs.nuc_blob, blob_len);          // sets s.nuc_base = offset of the blob in seq
+    std::vector<int64_t> ref_shift(n_mut);
+    std::vector<uint32_t> nuc_len(n_mut);
+    std::vector<uint64_t> nuc_dev_off(n_mut), new_pos(hs.new_pos, hs.new_pos + n_mut);
+    cell_size.assign(hs.chrom_size, hs.chrom_size + n_cells);
+    for (uint64_t k = 0; k < n_cells; k++) {
+        const uint64_t ref_len = hs.ref.chrom_lens[k % nc];
+        min_chrom = std::min(min_chrom, cell_size[k]);
+        max_chrom = std::max(max_chrom, cell_size[k]);
+        for (uint64_t m = cell_off[k]; m < cell_off[k + 1]; m++) {
+            // size_modifier (src/hap_classes.h:314-333)
+            int64_t smod = (m + 1 < cell_off[k + 1]) ? (int64_t)(hs.new_pos[m + 1] - hs.old_pos[m + 1])
+                                                     : (int64_t)(cell_size[k] - ref_len);
+            smod += (int64_t)(hs.old_pos[m] - hs.new_pos[m]);
+            const uint64_t have = hs.nuc_off[m + 1] - hs.nuc_off[m];
+            // equal new_pos happens: a deletion covers no haplotype position, so an edit right after it shares its new_pos
+            if (m > cell_off[k] && hs.new_pos[m] < hs.new_pos[m - 1]) throw Error(JK_ERR_ARG, "mutation new_pos must not decrease within a chromosome");
+            if (smod >= 0 && have < (uint64_t)smod + 1) throw Error(JK_ERR_ARG, "mutation has fewer nucleotides than its size modifier needs");
+            if (smod + 1 > 0x7fffffffLL) throw Error(JK_ERR_UNSUPPORTED, "insertion longer than 2^31 bases");
+            nuc_len[m] = smod >= 0 ? (uint32_t)(smod + 1) : 0u;
+            nuc_dev_off[m] = s.nuc_base + hs.nuc_off[m];
+            ref_shift[m] = (int64_t)hs.old_pos[m] - smod - (int64_t)hs.new_pos[m];
+            // the reference run after this mutation must stay inside the chromosome
+            const uint64_t run_end = (m + 1 < cell_off[k + 1]) ? hs.new_pos[m + 1] : cell_size[k];
+            const int64_t last_ref = (int64_t)run_end - 1 + ref_shift[m];
+            if (run_end > hs.new_pos[m] + nuc_len[m] && (last_ref < 0 || (uint64_t)last_ref >= ref_len))
+                throw Error(JK_ERR_ARG, "mutation table points outside the reference chromosome");
+        }
+    }
+    s.d_cell_off.upload(cell_off);
+    s.d_new_pos.upload(new_pos);
+    s.d_ref_shift.upload(ref_shift);
+    s.d_nuc_len.upload(nuc_len);
+    s.d_nuc_off.upload(nuc_dev_off);
+    s.d_cell_size.upload(cell_size);
+}
+
+static void set_hap_params(const jk_session& s, HapDev& h, uint32_t n_haps) {
+    h.cell_mut_off = s.d_cell_off.as<uint64_t>();
+    h.new_pos = s.d_new_pos.as<uint64_t>();
+    h.ref_shift = s.d_ref_shift.as<int64_t>();
+    h.nuc_len = s.d_nuc_len.as<uint32_t>();
+    h.nuc_off = s.d_nuc_off.as<uint64_t>();
+    h.cell_size = s.d_cell_size.as<uint64_t>();
+    h.bc_blob = s.d_bc_blob.as<uint8_t>();
+    h.bc_len = s.d_bc_len.as<uint32_t>();
+    h.n_haps = n_haps;
+}
+
+// ---- illumina_hap_cpp (src/hts_illumina.cpp:662-739), one set of output files (sep_files handled by
+// the caller: it opens one session per haplotype with one-hot probabilities, src/hts.h:512-552).
+static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illumina_args& a,
+                              const std::vector<double>& hap_probs, uint64_t n_reads, SeedReader& seeds) {
+    setup_model(s, a);
+    s.hap = true;
+    const uint32_t L = s.tables.read_length;
+    const uint64_t nh = hs.n_haps, nc = hs.ref.n_chroms;
+    if (nh == 0 || nc == 0) throw Error(JK_ERR_ARG, "haplotype set is empty");
+    if (nh * nc > 0x7fffffffULL) throw Error(JK_ERR_UNSUPPORTED, "too many (haplotype, chromosome) cells");
+    if (hap_probs.size() != nh) throw Error(JK_ERR_ARG, "haplotype_probs must have one entry per haplotype");
+    // barcodes: padded with "" to one per haplotype (src/hts_illumina.h:550)
+    std::vector<std::string> bcs(nh);
+    for (uint64_t h = 0; h < nh && h < a.n_barcodes; h++) bcs[h] = (a.barcodes && a.barcodes[h]) ? a.barcodes[h] : "";
+    size_t max_bc = 0;
+    for (const std::string& b : bcs) { check_barcode(b, L); max_bc = std::max(max_bc, b.size()); }
+
+    uint64_t min_chrom = ~0ULL, max_chrom = 0;
+    std::vector<uint64_t> cell_size;
+    upload_hap_tables(s, hs, min_chrom, max_chrom, cell_size);
+    const uint64_t n_cells = nh * nc;
+    {
+        std::vector<uint8_t> blob(nh * JK_MAX_BARCODE, 0);
+        std::vector<uint32_t> blen(nh);
+        for (uint64_t h = 0; h < nh; h++) {
+            blen[h] = (uint32_t)bcs[h].size();
+            for (size_t k = 0; k < bcs[h].size(); k++) blob[h * JK_MAX_BARCODE + k] = encode_base(bcs[h][k]);
+        }
+        s.d_bc_blob.upload(blob);
+        s.d_bc_len.upload(blen);
+    }
+    size_t max_hdr = 0;
+    {   // "@<haplotype>-<chromosome>-" per cell
+        std::vector<uint8_t> blob;
+        std::vector<uint32_t> hoff(n_cells + 1);
+        for (uint64_t k = 0; k < n_cells; k++) {
+            hoff[k] = (uint32_t)blob.size();
+            std::string h = std::string("@") + (hs.hap_names ? hs.hap_names[k / nc] : "") + "-" +
+                            (hs.ref.chrom_names ? hs.ref.chrom_names[k % nc] : "") + "-";
+            max_hdr = std::max(max_hdr, h.size());
+            blob.insert(blob.end(), h.begin(), h.end());
+        }
+        hoff[n_cells] = (uint32_t)blob.size();
+        s.d_hdr_blob.upload(blob);
+        s.d_hdr_off.upload(hoff);
+    }
+    const uint64_t frag_lb = std::min<uint64_t>(a.frag_len_min <= a.frag_len_max ? a.frag_len_min : a.frag_len_max, min_chrom);
+    if (frag_lb < std::max<uint64_t>(max_bc, 1))
+        throw Error(JK_ERR_UNSUPPORTED, "fragments shorter than the barcode (or empty) are not implemented on the GPU path");
+
+    // ---- lanes, quotas, seeds.  IlluminaHaplotypes::add_n_reads (src/hts_illumina.h:620-644) per lane:
+    // reads_per_group over haplotypes, then per haplotype reads_per_group over its chromosomes, then
+    // each read maker's own add_n_reads (halves the pair count again when paired; its result is never
+    // read by the haplotype path, but it consumes 8 seed words when it has reads).
+    std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, n_reads);
+    const uint64_t T = s.n_lanes_total;
+    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
+    std::vector<uint64_t> lane_reads(s.n_shard);
+    std::vector<uint32_t> vc((size_t)n_cells * s.n_shard, 0);
+    std::vector<std::vector<double>> chrom_probs(nh, std::vector<double>(nc));
+    for (uint64_t h = 0; h < nh; h++) for (uint64_t c = 0; c < nc; c++) chrom_probs[h][c] = (double)cell_size[h * nc + c];
+    DeferredSplits splits(&chrom_probs, vc.data(), s.n_shard, s.paired ? 2u : 1u);
+    for (uint64_t t = 0; t < T; t++) {
+        uint64_t n = per_lane[t];
+        if (s.paired) n /= 2;
+        const bool mine = t >= s.lane_begin && t < s.lane_end;
+        std::vector<uint64_t> hap_reads = reads_per_group(n, hap_probs, seeds);
+        for (uint64_t h = 0; h < nh; h++) {
+            if (mine) splits.add(hap_reads[h], seeds, (uint32_t)h, h * nc, t - s.lane_begin);
+            else if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }
+        }
+        for (uint64_t h = 0; h < nh; h++) {
+            uint64_t m = hap_reads[h];
+            if (s.paired) m /= 2;
+            if (m > 0) { uint32_t w[8]; seeds.take8(w); }
+        }
+        if (mine) lane_reads[t - s.lane_begin] = per_lane[t];
+    }
+    splits.flush();
+    s.seed_words_used = seeds.pos;
+
+    IlluminaKernelParams& P = s.kp;
+    P.bc_len = 0;
+    std::memset(P.barcode, 0, sizeof(P.barcode));
+    set_hap_params(s, P.h, (uint32_t)nh);
+    plan_pools_and_alloc(s, a, lane_reads, record_max(max_hdr, max_chrom, s.paired, L), lane_seeds, vc);
+}
+
+}  // namespace jk

@@ -1,0 +1,140 @@
+// api_launch.h -- one generate(): generator launches, scans and compaction on two streams
+// (part of the one translation unit jk_api.hip; see the include list there)
+#pragma once
+
+namespace jk {
+
+static void launch_generate(jk_session& s) {
+    JK_HIP(hipSetDevice(s.device));
+    JK_HIP(hipMemsetAsync(s.d_err.p, 0, 4, s.stream));
+    for (uint32_t e = 0; e < s.n_ends; e++) JK_HIP(hipMemsetAsync(s.d_base[e].p, 0, 8, s.stream));
+    size_t ev = 0;
+    JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+    JK_HIP(hipStreamWaitEvent(s.cp_stream, s.events[0], 0));
+    for (size_t b = 0; b < s.batches.size(); b++) {
+        if (s.abort_flag && *s.abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
+        const Batch& B = s.batches[b];
+        const int pp = (int)(b & 1);       // ping-pong pool set
+        if (s.pacbio) {
+            PacbioKernelParams Q = s.kpb;
+            Q.n_lanes = B.n_lanes;
+            Q.seeds = s.d_seeds.as<uint32_t>() + B.lane0 * 8;
+            Q.lane_reads = s.d_lane_reads.as<uint64_t>() + B.lane0;
+            Q.chrom_reads = s.d_chrom_reads.as<uint32_t>() + B.lane0;
+            Q.chrom_stride = (uint32_t)s.n_shard;
+            Q.pool_off = s.d_pool_off.as<uint64_t>() + s.batch_pool_off_index[b];
+            Q.pool = s.d_pool[pp][0].as<uint8_t>();
+            Q.lane_bytes = s.d_lane_bytes[0].as<uint64_t>() + B.lane0;
+            Q.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
+            if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));
+            JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+            const uint32_t pgrid = (B.n_lanes + 255) / 256;
+            if (s.hap) hipLaunchKernelGGL((pacbio_kernel<true>), dim3(pgrid), dim3(256), 0, s.stream, Q);
+            else hipLaunchKernelGGL((pacbio_kernel<false>), dim3(pgrid), dim3(256), 0, s.stream, Q);
+            JK_HIP(hipGetLastError());
+            JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+            JK_HIP(hipEventRecord(s.gen_done[b], s.stream));
+            JK_HIP(hipStreamWaitEvent(s.cp_stream, s.gen_done[b], 0));
+            const uint32_t nbp = (B.n_lanes + SCAN_BLOCK - 1) / SCAN_BLOCK;
+            uint64_t* lb = s.d_lane_bytes[0].as<uint64_t>() + B.lane0;
+            uint64_t* lo = s.d_lane_off[0].as<uint64_t>() + B.lane0;
+            uint64_t* bs = s.d_block_sums.as<uint64_t>();
+            uint64_t* base = s.d_base[0].as<uint64_t>() + b;
+            hipLaunchKernelGGL(scan_block_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lb, lo, bs, B.n_lanes);
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.cp_stream, bs, nbp, base);
+            hipLaunchKernelGGL(scan_add_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lo, bs, B.n_lanes);
+            hipLaunchKernelGGL(compact_linear_kernel, dim3(B.n_lanes), dim3(256), 0, s.cp_stream,
+                               s.d_pool[pp][0].as<uint8_t>(), Q.pool_off, lb, lo, s.d_out[0].as<uint8_t>(), base, B.n_lanes);
+            JK_HIP(hipGetLastError());
+            JK_HIP(hipEventRecord(s.cp_done[b], s.cp_stream));
+            continue;
+        }
+        IlluminaKernelParams P = s.kp;
+        P.n_lanes = B.n_lanes;
+        P.seeds = s.d_seeds.as<uint32_t>() + B.lane0 * 8;
+        P.lane_reads = s.d_lane_reads.as<uint64_t>() + B.lane0;
+        // quotas are laid out [chromosome or cell][lane of the shard]: row stride n_shard
+        P.chrom_reads = s.d_chrom_reads.as<uint32_t>() + B.lane0;
+        P.pool_off = s.d_pool_off.as<uint64_t>() + s.batch_pool_off_index[b];
+        for (uint32_t e = 0; e < 2; e++) {
+            P.pool[e] = e < s.n_ends ? s.d_pool[pp][e].as<uint8_t>() : nullptr;
+            P.lane_bytes[e] = e < s.n_ends ? s.d_lane_bytes[e].as<uint64_t>() + B.lane0 : nullptr;
+        }
+        P.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
+        P.evw = s.d_evw.as<uint64_t>() + (size_t)pp * s.evw_set;
+        P.chrom_stride = (uint32_t)s.n_shard;
+        // Two generators may be in flight (each has its own pool set and indel scratch): the next batch's
+        // workgroups then take over CUs as the current batch's finish instead of waiting for its slowest one.
+        hipStream_t gs = (s.two_gen_streams && (b & 1)) ? s.stream2 : s.stream;
+        if (s.two_gen_streams && b == 1) JK_HIP(hipStreamWaitEvent(s.stream2, s.events[0], 0));
+#ifndef JK_ILL_BLOCK
+#define JK_ILL_BLOCK 1024
+#endif
+        const uint32_t block = JK_ILL_BLOCK;
+        const uint32_t grid = (B.n_lanes + block - 1) / block;
+        // the pool set is free again once the compaction of batch b-2 has read it
+        if (b >= 2) JK_HIP(hipStreamWaitEvent(gs, s.cp_done[b - 2], 0));
+        JK_HIP(hipEventRecord(s.events[ev++], gs));
+#define JK_LAUNCH(LDS, NE, HAP, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP>), dim3(grid), dim3(block), SH, gs, P)
+        if (s.lds_tables) {
+            if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(true, 2, true, s.lds_launch); else JK_LAUNCH(true, 1, true, s.lds_launch); }
+            else       { if (s.n_ends == 2) JK_LAUNCH(true, 2, false, s.lds_launch); else JK_LAUNCH(true, 1, false, s.lds_launch); }
+        } else {
+            if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(false, 2, true, s.lds_launch); else JK_LAUNCH(false, 1, true, s.lds_launch); }
+            else       { if (s.n_ends == 2) JK_LAUNCH(false, 2, false, 0); else JK_LAUNCH(false, 1, false, 0); }
+        }
+#undef JK_LAUNCH
+        JK_HIP(hipGetLastError());
+        JK_HIP(hipEventRecord(s.events[ev++], gs));
+        JK_HIP(hipEventRecord(s.gen_done[b], gs));
+        JK_HIP(hipStreamWaitEvent(s.cp_stream, s.gen_done[b], 0));
+        const uint32_t nb = (B.n_lanes + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        for (uint32_t e = 0; e < s.n_ends; e++) {
+            uint64_t* lb = s.d_lane_bytes[e].as<uint64_t>() + B.lane0;
+            uint64_t* lo = s.d_lane_off[e].as<uint64_t>() + B.lane0;
+            uint64_t* bs = s.d_block_sums.as<uint64_t>();
+            uint64_t* base = s.d_base[e].as<uint64_t>() + b;
+            hipLaunchKernelGGL(scan_block_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s.cp_stream, lb, lo, bs, B.n_lanes);
+            hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.cp_stream, bs, nb, base);
+            hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s.cp_stream, lo, bs, B.n_lanes);
+            hipLaunchKernelGGL(compact_pools_kernel, dim3((B.n_lanes + 63) / 64), dim3(256), 0, s.cp_stream,
+                               s.d_pool[pp][e].as<uint8_t>(), P.pool_off, lb, lo, s.d_out[e].as<uint8_t>(), base, B.n_lanes);
+            JK_HIP(hipGetLastError());
+        }
+        JK_HIP(hipEventRecord(s.cp_done[b], s.cp_stream));
+    }
+    if (!s.batches.empty()) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[s.batches.size() - 1], 0));
+    JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+    JK_HIP(hipStreamSynchronize(s.stream));
+    JK_HIP(hipStreamSynchronize(s.cp_stream));
+
+    uint32_t err = 0;
+    JK_HIP(hipMemcpy(&err, s.d_err.p, 4, hipMemcpyDeviceToHost));
+    if (err & JK_KERR_PB_ALPHA) throw Error(JK_ERR_UNSUPPORTED, "chi-square shape n/2 < 1 (chi2_params_n) is not implemented on the GPU path");
+    if (err & JK_KERR_PB_MATH) throw Error(JK_ERR_UNSUPPORTED, "a PacBio parameter led to an exp/pow argument outside the range implemented on the GPU");
+    if (err & JK_KERR_PB_TOO_LONG) throw Error(JK_ERR_UNSUPPORTED, "a read was longer than the GPU path's cap (9 sigma of the log-normal, or it needed > 2x its length in reference positions)");
+    if (err & JK_KERR_PB_SPACE) throw Error(JK_ERR_UNSUPPORTED, "a read ran past its chromosome window (reads as long as their chromosome are not implemented on the GPU path)");
+    if ((err & JK_KERR_POOL_OVERFLOW) && s.pacbio) throw Error(JK_ERR_RETRY, "pool overflow");
+    if (err & JK_KERR_POOL_OVERFLOW) throw Error(JK_ERR_DEVICE, "internal error: a lane overflowed its pool region");
+    if (err & JK_KERR_TOO_MANY_DELETIONS) throw Error(JK_ERR_UNSUPPORTED, "a read needed more than 2x read_length reference positions (deletion probability too high for the GPU path)");
+    for (uint32_t e = 0; e < s.n_ends; e++)
+        JK_HIP(hipMemcpy(&s.bytes[e], s.d_base[e].as<uint64_t>() + s.batches.size(), 8, hipMemcpyDeviceToHost));
+    {
+        std::vector<uint64_t> made(s.n_shard);
+        if (s.n_shard) JK_HIP(hipMemcpy(made.data(), s.d_lane_made.p, s.n_shard * 8, hipMemcpyDeviceToHost));
+        s.reads_made = 0;
+        for (uint64_t v : made) s.reads_made += v;
+    }
+    float t = 0;
+    double gen = 0, rest = 0;
+    for (size_t b = 0; b < s.batches.size(); b++) {
+        JK_HIP(hipEventElapsedTime(&t, s.events[1 + 2 * b], s.events[2 + 2 * b]));
+        gen += t;
+    }
+    JK_HIP(hipEventElapsedTime(&t, s.events[0], s.events[ev - 1]));
+    rest = t - gen;
+    s.ms[0] = gen; s.ms[1] = rest; s.ms[2] = t;
+    s.generated = true;
+}
+
+}  // namespace jk

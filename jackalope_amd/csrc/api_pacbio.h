@@ -1,0 +1,245 @@
+// api_pacbio.h -- host set-up of the PacBio sessions
+// (part of the one translation unit jk_api.hip; see the include list there)
+#pragma once
+
+namespace jk {
+
+// ---- pacbio_ref_cpp / pacbio_hap_cpp (src/hts_pacbio.cpp:579-715): host set-up -----------------------
+// Everything that depends only on the run's parameters or on an integer is tabulated here with the host's
+// libm (exactly what the reference calls) and the nmath restatements of jk_nmath.h.
+struct PacbioHostModel {
+    std::vector<uint64_t> len_thresh; std::vector<uint32_t> len_alias; std::vector<uint64_t> lens;
+    std::vector<double> thr_tab; std::vector<PassEntry> pass_tab;
+    double min_exp = 0;
+    uint64_t len_hi = 0;      // pool sizing: a read length few reads exceed
+    uint64_t len_cap = 0;     // hard cap (event scratch)
+};
+
+static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a, uint64_t max_chrom) {
+    set_compression(s, a.compress, a.comp_method);
+    if (!a.chi2_params_n || !a.chi2_params_s || !a.sqrt_params || !a.norm_params) throw Error(JK_ERR_ARG, "PacBio parameter vectors must not be NULL");
+    s.pacbio = true; s.paired = false; s.n_ends = 1;
+    s.out_prefix = a.out_prefix ? a.out_prefix : "";
+    s.abort_flag = a.abort_flag;
+    s.device = a.device;
+    JK_HIP(hipSetDevice(s.device));
+    JK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    JK_HIP(hipStreamCreateWithFlags(&s.cp_stream, hipStreamNonBlocking));
+
+    PacbioHostModel M;
+    PacbioKernelParams& P = s.kpb;
+    // read lengths (PacBioReadLenSampler, src/hts_pacbio.h:45-109)
+    if (a.n_read_lens == 0) {
+        P.use_lognormal = 1;
+        P.ln_mu = std::log(a.scale); P.ln_sigma = a.sigma; P.ln_loc = a.loc;
+        P.min_read_len = std::ceil(a.min_read_len);
+        if (P.min_read_len < 1) P.min_read_len = 1;
+        const double hi = std::exp(P.ln_mu + 4.0 * a.sigma) + a.loc, cap = std::exp(P.ln_mu + 9.0 * a.sigma) + a.loc;
+        M.len_hi = (uint64_t)std::max(hi, P.min_read_len + 1.0);
+        M.len_cap = (uint64_t)std::max(cap, P.min_read_len + 1.0);
+    } else {
+        if (!a.read_probs || !a.read_lens) throw Error(JK_ERR_ARG, "Probability and read lengths vector should be the same length.");
+        P.use_lognormal = 0;
+        AliasTable at = alias_build(std::vector<double>(a.read_probs, a.read_probs + a.n_read_lens));
+        for (uint64_t i = 0; i < a.n_read_lens; i++) {
+            Threshold th = threshold_lt(at.prob[i]);
+            M.len_thresh.push_back(th.all ? ~uint64_t(0) : th.th);
+            M.len_alias.push_back(th.all ? (uint32_t)i : (uint32_t)at.alias[i]);
+            M.lens.push_back(a.read_lens[i]);
+            M.len_hi = std::max(M.len_hi, a.read_lens[i]);
+        }
+        M.len_cap = M.len_hi;
+        if (a.n_read_lens >= (1ULL << 31)) throw Error(JK_ERR_UNSUPPORTED, "too many custom read lengths");
+        P.n_lens = (uint32_t)a.n_read_lens;
+    }
+    M.len_hi = std::min(M.len_hi, max_chrom);
+    M.len_cap = std::min(M.len_cap, max_chrom);
+    // passes (PacBioPassSampler): qchisq(0.9925, n(L)) for every read length that changes n
+    for (int i = 0; i < 3; i++) P.cn[i] = a.chi2_params_n[i];
+    for (int i = 0; i < 5; i++) P.cs[i] = a.chi2_params_s[i];
+    P.max_passes_d = static_cast<double>(a.max_passes);
+    if (a.max_passes < 1 || a.max_passes > 100000) throw Error(JK_ERR_ARG, "max_passes out of range");
+    {
+        const double n2 = P.cn[2];
+        uint64_t cap = n2 >= 1 ? (uint64_t)std::min(std::floor(n2), (double)M.len_cap) : 0;
+        if (cap > (64ULL << 20)) throw Error(JK_ERR_UNSUPPORTED, "chi2_params_n[3] too large for the GPU path's threshold table");
+        M.thr_tab.resize(cap + 2);
+        for (uint64_t L = 0; L <= cap + 1; L++) {
+            const double Ld = (L <= cap) ? (double)L : std::max((double)(cap + 1), n2);   // last entry: the capped value
+            double n = P.cn[0] * std::min(Ld, n2) + P.cn[1];
+            if (n < 0.001) n = 0.001;
+            M.thr_tab[L] = qchisq_upper_tail_point(0.9925, n);
+        }
+        P.thr_cap = (uint32_t)(cap + 1);
+    }
+    // qualities/errors (PacBioQualityError)
+    P.np0 = a.norm_params[0]; P.np1 = a.norm_params[1]; P.sp1 = a.sqrt_params[1];
+    P.prob_ins = a.prob_ins; P.prob_del = a.prob_del; P.prob_subst = a.prob_subst;
+    {   // calc_min_exp (src/hts_pacbio.cpp:50-91)
+        auto total_at = [&](double e) { return std::pow(a.prob_ins, e) + std::pow(a.prob_del, e) + std::pow(a.prob_subst, e); };
+        double min_exp_ = 1, total = total_at(min_exp_), left, right;
+        if (total < a.prob_thresh) {
+            while (total < a.prob_thresh) { min_exp_ /= 2; total = total_at(min_exp_); }
+            left = min_exp_; right = min_exp_ * 2;
+        } else {
+            while (total > a.prob_thresh) { min_exp_ *= 2; total = total_at(min_exp_); }
+            left = min_exp_ / 2; right = min_exp_;
+        }
+        for (int i = 0; i < 15; i++) {
+            const double m = (left + right) / 2;
+            total = total_at(m);
+            if (total == a.prob_thresh) { min_exp_ = m; break; }
+            else if (total > a.prob_thresh) { left = m; min_exp_ = (m + right) / 2; }
+            else { right = m; min_exp_ = (left + m) / 2; }
+        }
+        M.min_exp = min_exp_;
+    }
+    M.pass_tab.resize(a.max_passes + 2);
+    for (uint64_t k = 0; k < M.pass_tab.size(); k++) {
+        const double passes = (double)k;
+        PassEntry& e = M.pass_tab[k];
+        e.sig = 1 / (1 + std::pow(2, (-2.5 / 3 * passes + 6.5 / 3)));                 // sigmoid (hts_pacbio.h:333-335)
+        e.sqrtv = std::sqrt(passes + a.sqrt_params[0]);
+        const double lower_thresh = (M.min_exp - (e.sqrtv - a.sqrt_params[1])) / e.sig;   // update_probs (hts_pacbio.cpp:101-104)
+        e.a_bar = (lower_thresh - a.norm_params[0]) / a.norm_params[1];
+        if (lower_thresh < (a.norm_params[0] + 5 * a.norm_params[1])) {
+            e.method = 0;
+            e.p = pnorm_std(e.a_bar);
+            jk_x87_one_minus(e.p, &e.c_m, &e.c_e);
+        } else { e.method = 1; e.p = 0; e.c_m = 0; e.c_e = 0; }
+    }
+    {   // dup < prob_dup
+        Threshold t = threshold_lt(a.prob_dup);
+        P.th_dup = t.th; P.dup_all = t.all;
+    }
+    P.pool_size = a.read_pool_size;
+    return M;
+}
+
+static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioHostModel& M, size_t max_hdr, uint64_t max_chrom,
+                          const std::vector<uint64_t>& lane_reads, const std::vector<uint32_t>& lane_seeds,
+                          const std::vector<uint32_t>& quotas) {
+    // pools: sized for reads of length len_hi; the kernel checks before every record and the session retries
+    // with a larger scale if a lane ran out (s.pool_scale)
+    const uint64_t rec = max_hdr + n_digits(max_chrom) + 3 + 2 * M.len_hi + 8;
+    std::vector<uint64_t> lane_cap(s.n_shard);
+    for (uint64_t l = 0; l < s.n_shard; l++)       // per-lane regions are contiguous and hold whole 128-byte lines
+        lane_cap[l] = align_up((uint64_t)((double)(lane_reads[l] * rec) * s.pool_scale) + 2 * M.len_cap + 64, 128) + 128;
+    const uint32_t max_lanes = plan_pools_common(s, max_batch_bytes ? max_batch_bytes : (48ULL << 30), 1ULL << 18,
+                                                 lane_cap, lane_reads, lane_seeds, quotas);
+    s.ev_words = (uint32_t)((2 * M.len_cap + 64 + 31) / 32);
+    s.d_ev2.alloc((size_t)s.ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
+    s.d_len_thresh.upload(M.len_thresh); s.d_len_alias.upload(M.len_alias); s.d_lens.upload(M.lens);
+    s.d_thr_tab.upload(M.thr_tab); s.d_pass_tab.upload(M.pass_tab);
+    PacbioKernelParams& P = s.kpb;
+    P.g.seq = s.d_seq.as<uint8_t>();
+    P.g.chrom_off = s.d_chrom_off.as<uint64_t>();
+    P.g.chrom_len = s.d_chrom_len.as<uint64_t>();
+    P.g.hdr_blob = s.d_hdr_blob.as<uint8_t>();
+    P.g.hdr_off = s.d_hdr_off.as<uint32_t>();
+    P.g.n_chroms = s.n_chroms;
+    P.ev = s.d_ev2.as<uint64_t>(); P.ev_words = s.ev_words;
+    P.err = s.d_err.as<uint32_t>();
+    P.len_thresh = s.d_len_thresh.as<uint64_t>(); P.len_alias = s.d_len_alias.as<uint32_t>(); P.lens = s.d_lens.as<uint64_t>();
+    P.thr_tab = s.d_thr_tab.as<double>(); P.pass_tab = s.d_pass_tab.as<PassEntry>();
+}
+
+static void upload_headers(jk_session& s, const std::vector<std::string>& hdrs, size_t& max_hdr) {
+    std::vector<uint8_t> blob;
+    std::vector<uint32_t> hoff(hdrs.size() + 1);
+    for (size_t k = 0; k < hdrs.size(); k++) {
+        hoff[k] = (uint32_t)blob.size();
+        max_hdr = std::max(max_hdr, hdrs[k].size());
+        blob.insert(blob.end(), hdrs[k].begin(), hdrs[k].end());
+    }
+    hoff[hdrs.size()] = (uint32_t)blob.size();
+    s.d_hdr_blob.upload(blob);
+    s.d_hdr_off.upload(hoff);
+}
+
+static void open_pacbio_ref(jk_session& s, const jk_ref_genome& g, const jk_pacbio_args& a, SeedReader& seeds) {
+    uint64_t max_chrom = 0;
+    for (uint64_t i = 0; i < g.n_chroms; i++) max_chrom = std::max<uint64_t>(max_chrom, g.chrom_lens[i]);
+    PacbioHostModel M = setup_pacbio_model(s, a, max_chrom);
+    upload_genome(s, g, nullptr, 0);
+    const std::string gname = g.name ? g.name : "REF";
+    std::vector<std::string> hdrs;
+    for (uint64_t i = 0; i < g.n_chroms; i++) hdrs.push_back("@" + gname + "-" + (g.chrom_names ? g.chrom_names[i] : "") + "-");
+    size_t max_hdr = 0;
+    upload_headers(s, hdrs, max_hdr);
+    // lanes, quotas, seeds (src/hts.h:334-353 with n_read_ends = 1; PacBioOneGenome::add_n_reads, hts_pacbio.h:499-503)
+    std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, a.n_reads);
+    const uint64_t T = s.n_lanes_total;
+    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
+    std::vector<uint64_t> lane_reads(s.n_shard);
+    std::vector<uint32_t> chrom_reads((size_t)s.n_chroms * s.n_shard, 0);
+    const std::vector<std::vector<double>> chrom_probs(1, std::vector<double>(g.chrom_lens, g.chrom_lens + g.n_chroms));
+    DeferredSplits splits(&chrom_probs, chrom_reads.data(), s.n_shard, 1u);
+    for (uint64_t t = 0; t < T; t++) {
+        const uint64_t n = per_lane[t];
+        const bool mine = t >= s.lane_begin && t < s.lane_end;
+        if (!mine) { if (n > 0) { uint32_t w[8]; seeds.take8(w); } continue; }
+        const uint64_t l = t - s.lane_begin;
+        lane_reads[l] = n;
+        splits.add(n, seeds, 0, 0, l);
+    }
+    splits.flush();
+    s.seed_words_used = seeds.pos;
+    const uint64_t mbb = a.max_batch_bytes;
+    jk_session* sp = &s;
+    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, lane_reads, lane_seeds, chrom_reads); };
+    s.replan();
+}
+
+static void open_pacbio_hap(jk_session& s, const jk_hap_set& hs, const jk_pacbio_args& a,
+                            const std::vector<double>& hap_probs, uint64_t n_reads, SeedReader& seeds) {
+    const uint64_t nh = hs.n_haps, nc = hs.ref.n_chroms;
+    if (nh == 0 || nc == 0) throw Error(JK_ERR_ARG, "haplotype set is empty");
+    if (hap_probs.size() != nh) throw Error(JK_ERR_ARG, "haplotype_probs must have one entry per haplotype");
+    uint64_t max_c = 0;
+    for (uint64_t k = 0; k < nh * nc; k++) max_c = std::max<uint64_t>(max_c, hs.chrom_size[k]);
+    PacbioHostModel M = setup_pacbio_model(s, a, max_c);
+    s.hap = true;
+    uint64_t min_chrom = ~0ULL, max_chrom = 0;
+    std::vector<uint64_t> cell_size;
+    upload_hap_tables(s, hs, min_chrom, max_chrom, cell_size);
+    {   // no barcodes on this path
+        std::vector<uint8_t> blob(nh * JK_MAX_BARCODE, 0); std::vector<uint32_t> blen(nh, 0);
+        s.d_bc_blob.upload(blob); s.d_bc_len.upload(blen);
+    }
+    const uint64_t n_cells = nh * nc;
+    std::vector<std::string> hdrs;
+    for (uint64_t k = 0; k < n_cells; k++)
+        hdrs.push_back(std::string("@") + (hs.hap_names ? hs.hap_names[k / nc] : "") + "-" + (hs.ref.chrom_names ? hs.ref.chrom_names[k % nc] : "") + "-");
+    size_t max_hdr = 0;
+    upload_headers(s, hdrs, max_hdr);
+    // PacBioHaplotypes::add_n_reads (src/hts_pacbio.h:683-700)
+    std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, n_reads);
+    const uint64_t T = s.n_lanes_total;
+    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
+    std::vector<uint64_t> lane_reads(s.n_shard);
+    std::vector<uint32_t> vc((size_t)n_cells * s.n_shard, 0);
+    std::vector<std::vector<double>> chrom_probs(nh, std::vector<double>(nc));
+    for (uint64_t h = 0; h < nh; h++) for (uint64_t c = 0; c < nc; c++) chrom_probs[h][c] = (double)cell_size[h * nc + c];
+    DeferredSplits splits(&chrom_probs, vc.data(), s.n_shard, 1u);
+    for (uint64_t t = 0; t < T; t++) {
+        const uint64_t n = per_lane[t];
+        const bool mine = t >= s.lane_begin && t < s.lane_end;
+        std::vector<uint64_t> hap_reads = reads_per_group(n, hap_probs, seeds);
+        for (uint64_t h = 0; h < nh; h++) {
+            if (mine) splits.add(hap_reads[h], seeds, (uint32_t)h, h * nc, t - s.lane_begin);
+            else if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }
+        }
+        for (uint64_t h = 0; h < nh; h++) if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }   // read_makers[h].add_n_reads
+        if (mine) lane_reads[t - s.lane_begin] = n;
+    }
+    splits.flush();
+    s.seed_words_used = seeds.pos;
+    set_hap_params(s, s.kpb.h, (uint32_t)nh);
+    const uint64_t mbb = a.max_batch_bytes;
+    jk_session* sp = &s;
+    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, lane_reads, lane_seeds, vc); };
+    s.replan();
+}
+
+}  // namespace jk

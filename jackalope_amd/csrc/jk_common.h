@@ -1,0 +1,62 @@
+// jk_common.h -- error type, HIP call check, device buffer, small helpers shared by the host code
+// (part of the one translation unit jk_api.hip; see the include list there)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../include/jackalope_hip.h"
+#include "jk_host.h"
+
+namespace jk {
+
+static thread_local std::string g_last_error;
+
+#define JK_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            throw Error(JK_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void alloc(size_t bytes) {
+        release();
+        if (bytes == 0) bytes = 16;
+        JK_HIP(hipMalloc(&p, bytes));
+        n = bytes;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+    template <typename T> void upload(const std::vector<T>& v) {
+        alloc(v.size() * sizeof(T));
+        if (!v.empty()) JK_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+};
+
+constexpr int JK_ERR_RETRY = 1000;   // internal: PacBio pools were too small, regenerate with larger ones
+
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+static inline uint32_t n_digits(uint64_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; d++; } return d; }
+
+struct Batch {
+    uint64_t lane0;        // first lane (relative to the shard)
+    uint32_t n_lanes;
+    uint64_t pool_bytes;   // per read end
+};
+
+template <typename F>
+static int guarded(F f) {
+    try { f(); g_last_error.clear(); return JK_OK; }
+    catch (const Error& e) { g_last_error = e.what(); return e.code; }
+    catch (const std::bad_alloc&) { g_last_error = "out of host memory"; return JK_ERR_DEVICE; }
+    catch (const std::exception& e) { g_last_error = e.what(); return JK_ERR_ARG; }
+}
+
+
+}  // namespace jk

@@ -1,0 +1,70 @@
+// jk_session.h -- state of one sequencing run (what jk_*_open returns)
+// (part of the one translation unit jk_api.hip; see the include list there)
+#pragma once
+
+
+#ifndef JK_ILL_BLOCK
+#define JK_ILL_BLOCK 1024     // threads per generator workgroup (one workgroup per CU when the tables sit in LDS)
+#endif
+
+using namespace jk;
+
+struct jk_session {
+    int device = 0;
+    hipStream_t stream = nullptr;      // generator kernels
+    hipStream_t cp_stream = nullptr;   // scan + compaction of the previous batch, overlapping the next one
+    hipStream_t stream2 = nullptr;     // Illumina: generator launches of odd batches (see launch_generate)
+    bool two_gen_streams = false;
+    uint32_t n_ends = 1;
+    bool paired = false;
+    std::string out_prefix;
+    // genome
+    DevBuf d_seq, d_chrom_off, d_chrom_len, d_hdr_blob, d_hdr_off;
+    uint32_t n_chroms = 0;
+    // tables
+    IlluminaTables tables;
+    DevBuf d_info, d_thresh, d_quals, d_mm;
+    bool lds_tables = false;
+    size_t lds_bytes = 0, lds_launch = 0, evw_set = 0;
+    uint32_t lds_seg_off = 0;
+    bool hap = false;
+    int compress = 0;          // 0 = plain FASTQ, 1..9 = compression level
+    bool bgzip = true;         // comp_method: "bgzip" (BGZF blocks) or "gzip"
+    bool host_deflate = false; // comp_method "bgzip-host": BGZF blocks deflated by zlib on the host at level `compress`
+    bool pacbio = false;
+    PacbioKernelParams kpb{};
+    DevBuf d_len_thresh, d_len_alias, d_lens, d_thr_tab, d_pass_tab, d_ev2;
+    uint32_t ev_words = 0;
+    uint64_t nuc_base = 0;     // offset of the haplotypes' nucleotide blob inside d_seq
+    double pool_scale = 1.25;  // PacBio: pool capacity relative to the expected bytes (grown on overflow)
+    std::function<void()> replan;   // PacBio: re-plan pools after pool_scale changed
+    DevBuf d_cell_off, d_new_pos, d_ref_shift, d_nuc_len, d_nuc_off, d_cell_size, d_bc_blob, d_bc_len;
+    // lanes of this shard
+    uint64_t n_lanes_total = 0, lane_begin = 0, lane_end = 0, n_shard = 0;
+    std::vector<uint64_t> pool_off_host;          // per batch-relative offsets, concatenated per batch (n+1 each)
+    DevBuf d_seeds, d_lane_reads, d_chrom_reads, d_pool_off;
+    std::vector<Batch> batches;
+    std::vector<uint64_t> batch_pool_off_index;   // index into d_pool_off of each batch's first entry
+    DevBuf d_pool[2][2] /* [ping-pong][end] */, d_out[2], d_lane_bytes[2], d_lane_off[2], d_block_sums, d_base[2], d_lane_made, d_evw, d_err;
+    uint64_t out_cap = 0;
+    IlluminaKernelParams kp{};                    // template, per-batch fields filled at launch
+    // results of the last generate()
+    uint64_t bytes[2] = {0, 0};
+    uint64_t reads_made = 0;
+    double ms[3] = {0, 0, 0};
+    bool generated = false;
+    uint64_t seed_words_used = 0;
+    const volatile int32_t* abort_flag = nullptr;
+    std::vector<hipEvent_t> events;       // [0] start, [1+2b] / [2+2b] around generator b, last = end
+    std::vector<hipEvent_t> gen_done, cp_done;   // per batch, for the two-stream hand-off
+
+    ~jk_session() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        for (hipEvent_t e : gen_done) (void)hipEventDestroy(e);
+        for (hipEvent_t e : cp_done) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (cp_stream) (void)hipStreamDestroy(cp_stream);
+        if (stream2) (void)hipStreamDestroy(stream2);
+    }
+};
+
