@@ -309,37 +309,46 @@ pacbio_kernel(PacbioKernelParams P) {
         if (err) break;
 
         // ---- pass 1: one draw per position (PacBioQualityError::sample, src/hts_pacbio.h:292-317)
-        uint64_t cur = 0, pos = 0, extra = chrom_len - L, n_ins = 0, n_del = 0;
+        // Counters are 32-bit (a read is shorter than 2^31 positions: the event scratch is), the spare chromosome
+        // length is clamped to 2^31-1 (it only matters when it reaches 0, at most one step per position), and the
+        // side of the split is a per-iteration select of the cut points instead of state that is switched.
+        uint32_t cur = 0, pos = 0, n_ins = 0, n_del = 0;
+        if (L > 0x7fffffffULL) { err |= JK_KERR_PB_TOO_LONG; break; }
         {
             // u > cum[2]  <=>  x >= t_none ; u < cum[0]  <=>  x < t_ins ; u < cum[1]  <=>  x < t_del
             uint64_t tL[3], tR[3]; bool aL[3], aR[3];
             tL[0] = cut_point<true>(cumL[2], &aL[0]); tL[1] = cut_point<false>(cumL[0], &aL[1]); tL[2] = cut_point<false>(cumL[1], &aL[2]);
             tR[0] = cut_point<true>(cumR[2], &aR[0]); tR[1] = cut_point<false>(cumR[0], &aR[1]); tR[2] = cut_point<false>(cumR[1], &aR[2]);
-            uint64_t t_none = tL[0], t_ins = tL[1], t_del = tL[2];
-            bool never_none = aL[0], all_ins = aL[1], all_del = aL[2];
-            auto go_right = [&]() { t_none = tR[0]; t_ins = tR[1]; t_del = tR[2]; never_none = aR[0]; all_ins = aR[1]; all_del = aR[2]; };
+            // bit 0: never "none", bit 1: always insertion, bit 2: always deletion (cut points that cover every draw)
+            const uint32_t fL = (aL[0] ? 1u : 0u) | (aL[1] ? 2u : 0u) | (aL[2] ? 4u : 0u);
+            const uint32_t fR = (aR[0] ? 1u : 0u) | (aR[1] ? 2u : 0u) | (aR[2] ? 4u : 0u);
+            const uint32_t L32 = (uint32_t)L;
+            const uint32_t split32 = split_pos > 0xffffffffULL ? 0xffffffffu : (uint32_t)split_pos;
+            const uint64_t spare = chrom_len - L;
+            uint32_t extra = spare > 0x7fffffffULL ? 0x7fffffffu : (uint32_t)spare;
             uint64_t word = 0;
-            while (cur < L) {
-                if (cur == split_pos) go_right();
+            while (cur < L32) {
+                const bool right = cur >= split32;        // (the reference switches sides when cur reaches split_pos)
+                const uint64_t t_none = right ? tR[0] : tL[0], t_ins = right ? tR[1] : tL[1], t_del = right ? tR[2] : tL[2];
+                const uint32_t f = right ? fR : fL;
                 const uint64_t x = rng();
                 // same decision tree as the reference (src/hts_pacbio.h:296-314), written without divergent branches
-                const bool none = !never_none && x >= t_none;
-                const bool ins = !none && (all_ins || x < t_ins);
-                const bool del = !none && !ins && (all_del || x < t_del);
+                const bool none = !(f & 1u) && x >= t_none;
+                const bool ins = !none && ((f & 2u) || x < t_ins);
+                const bool del = !none && !ins && ((f & 4u) || x < t_del);
                 const bool sub = !none && !ins && !del;
-                const bool ins_rec = ins && (cur < L - 1);           // an insertion at the last base is not recorded
-                const bool del_rec = del && (extra > 0);              // nor a deletion without spare chromosome
-                const uint64_t type = ins_rec ? 1u : (del_rec ? 2u : (sub ? 3u : 0u));
+                const bool ins_rec = ins && (cur < L32 - 1u);        // an insertion at the last base is not recorded
+                const bool del_rec = del && (extra > 0u);             // nor a deletion without spare chromosome
+                const uint32_t type = ins_rec ? 1u : (del_rec ? 2u : (sub ? 3u : 0u));
                 n_ins += ins_rec ? 1u : 0u; n_del += del_rec ? 1u : 0u;
                 extra = extra + (ins_rec ? 1u : 0u) - (del_rec ? 1u : 0u);
-                if (ins_rec) { cur++; if (cur == split_pos) go_right(); }
-                cur += del ? 0u : 1u;
+                cur += (ins_rec ? 1u : 0u) + (del ? 0u : 1u);
                 if (pos >= max_pos) { err |= JK_KERR_PB_TOO_LONG; break; }
-                word |= type << (2u * (pos & 31u));
+                word |= (uint64_t)type << (2u * (pos & 31u));
                 pos++;
-                if ((pos & 31u) == 0) { evl[(pos >> 5) * ev_stride - ev_stride] = word; word = 0; }
+                if ((pos & 31u) == 0) { evl[(size_t)((pos >> 5) - 1u) * ev_stride] = word; word = 0; }
             }
-            if (pos & 31u) evl[(pos >> 5) * ev_stride] = word;
+            if (pos & 31u) evl[(size_t)(pos >> 5) * ev_stride] = word;
         }
         if (err) break;
         uint64_t space = L + n_del - n_ins;
