@@ -140,10 +140,10 @@ __device__ __forceinline__ void rs_drain(RingStream& s) {
         s.widx = (s.widx + 1u) & 31u; s.pend++;
     }
 }
-// append `n` (0..2) bytes given in the low bytes of `two`; the caller keeps the ring from overflowing
-// (one word at most is produced per call)
-__device__ __forceinline__ void rs_put2(RingStream& s, uint32_t two, uint32_t n) {
-    s.acc |= (uint64_t)two << (8u * s.nacc);
+// append `n` (0..4) bytes given in the low bytes of `bytes`; the caller keeps the ring from overflowing
+// (one word at most is produced per call: fewer than 4 bytes are pending on entry)
+__device__ __forceinline__ void rs_put2(RingStream& s, uint32_t bytes, uint32_t n) {
+    s.acc |= (uint64_t)bytes << (8u * s.nacc);
     s.nacc += n; s.pos += n;
     rs_drain(s);
 }
@@ -475,8 +475,8 @@ pacbio_kernel(PacbioKernelParams P) {
                 // the reference would read stale buffer bytes past the read's window here (only reachable when a
                 // read is as long as its chromosome); refuse instead of inventing bytes
                 if (p2 + kcut > space) { err |= JK_KERR_PB_SPACE; break; }
-                for (uint32_t k = 0; k < kcut; k++) {                 // (lanes near the end of their read run fewer)
-                    if (__builtin_amdgcn_ballot_w64(o.pend >= 31u)) rs_flush(o);
+                // bytes of position p2 + k: up to two, in the low bytes, with their count in bits 16..17
+                auto emit = [&](uint32_t k) -> uint32_t {
                     if (HAP && p2 + k >= seg_end) seg_enter(p2 + k);
                     const uint32_t c = src_next();
                     // character of read[p2 + k] as the reference sees it (cmp_map for the reverse strand)
@@ -491,8 +491,23 @@ pacbio_kernel(PacbioKernelParams P) {
                     const uint32_t sub_ch = is_nul ? 0u : (is_nt ? base_char(code + (code >= nt ? 1u : 0u)) : (uint32_t)'N');
                     const uint32_t b0 = is_sub ? sub_ch : ch;
                     const uint32_t nb = is_del ? 0u : (is_ins ? 2u : 1u);
-                    rs_put2(o, is_del ? 0u : (b0 | (is_ins ? (ins_ch << 8) : 0u)), nb);
-                    cur2 += nb;
+                    return (is_del ? 0u : (b0 | (is_ins ? (ins_ch << 8) : 0u))) | (nb << 16);
+                };
+                // two positions per ring check: they add at most 4 bytes to fewer than 4 pending ones, so one
+                // word at most leaves the shift register (lanes near the end of their read run fewer positions)
+                uint32_t k = 0;
+                for (; k + 2u <= kcut; k += 2u) {
+                    if (__builtin_amdgcn_ballot_w64(o.pend >= 31u)) rs_flush(o);
+                    const uint32_t r0 = emit(k), r1 = emit(k + 1u);
+                    const uint32_t n0 = r0 >> 16, n1 = r1 >> 16;
+                    rs_put2(o, (r0 & 0xffffu) | ((r1 & 0xffffu) << (8u * n0)), n0 + n1);
+                    cur2 += n0 + n1;
+                }
+                if (k < kcut) {
+                    if (__builtin_amdgcn_ballot_w64(o.pend >= 31u)) rs_flush(o);
+                    const uint32_t r0 = emit(k);
+                    rs_put2(o, r0 & 0xffffu, r0 >> 16);
+                    cur2 += r0 >> 16;
                 }
                 p2 += kcut;
             }
