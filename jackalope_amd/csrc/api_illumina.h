@@ -58,7 +58,7 @@ static void setup_model(jk_session& s, const jk_illumina_args& a) {
     s.abort_flag = a.abort_flag;
     s.device = a.device;
     JK_HIP(hipSetDevice(s.device));
-    JK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    create_generator_stream(s);
     JK_HIP(hipStreamCreateWithFlags(&s.cp_stream, hipStreamNonBlocking));
     JK_HIP(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
     if (const char* e = std::getenv("JK_TWO_GEN_STREAMS")) s.two_gen_streams = std::atoi(e) != 0;

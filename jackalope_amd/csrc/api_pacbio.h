@@ -23,7 +23,7 @@ static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a
     s.abort_flag = a.abort_flag;
     s.device = a.device;
     JK_HIP(hipSetDevice(s.device));
-    JK_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    create_generator_stream(s);
     JK_HIP(hipStreamCreateWithFlags(&s.cp_stream, hipStreamNonBlocking));
 
     PacbioHostModel M;
