@@ -429,7 +429,7 @@ def main():
                                  % (1206.0 * pairs_rank / n_launch / kern_s)},
             "device_ms_per_step": round(all_ms / a.steps, 3),
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:            # the CPU baseline is reported at N = 1 only
             cores = min(os.cpu_count() or 1, 64)
             sample = a.cpu_sample_pairs or min(200_000 * cores, 12_000_000)     # about 15-20 s of CPU work
             p1, p2 = ja.read_profile(None, None, read_length, 1), ja.read_profile(None, None, read_length, 2)
