@@ -151,7 +151,7 @@ class IlluminaSession:
 def make_args(out_prefix, n_reads, paired, matepair, prof1, prof2, ins_prob1, del_prob1, ins_prob2, del_prob2,
               frag_len_shape, frag_len_scale, frag_len_min, frag_len_max, barcodes, prob_dup, n_threads,
               read_pool_size, words, compress=0, comp_method="bgzip", sep_files=False, haplotype_probs=None,
-              lane_begin=0, lane_end=0, device=0, max_batch_bytes=0):
+              lane_begin=0, lane_end=0, device=0, max_batch_bytes=0, seed_fn=None, abort_flag=None):
     """Assemble jk_illumina_args; returns (struct, keep-alive list)."""
     a = _abi.IlluminaArgs()
     keep = []
@@ -183,10 +183,27 @@ def make_args(out_prefix, n_reads, paired, matepair, prof1, prof2, ins_prob1, de
     keep.append(arr)
     a.barcodes = arr
     a.n_barcodes = len(bcs)
-    words = np.ascontiguousarray(words, dtype=np.uint32)
-    keep.append(words)
-    a.seeds.words = words.ctypes.data_as(C.POINTER(C.c_uint32))
-    a.seeds.n_words = words.size
+    if seed_fn is not None:
+        # the form the Rcpp shim uses: a callback that fills the next 8 words (Rcpp::runif there)
+        def _cb(_user, out8):
+            try:
+                w = seed_fn()
+                for i in range(8):
+                    out8[i] = int(w[i])
+                return 0
+            except Exception:
+                return 1
+        cb = _abi.SEED_FN(_cb)
+        keep.append(cb)
+        a.seeds.fn = cb
+    else:
+        words = np.ascontiguousarray(words, dtype=np.uint32)
+        keep.append(words)
+        a.seeds.words = words.ctypes.data_as(C.POINTER(C.c_uint32))
+        a.seeds.n_words = words.size
+    if abort_flag is not None:                # numpy int32 array of one element, polled between batches
+        keep.append(abort_flag)
+        a.abort_flag = abort_flag.ctypes.data_as(C.POINTER(C.c_int32))
     a.lane_begin, a.lane_end = int(lane_begin), int(lane_end)
     a.device = int(device)
     a.max_batch_bytes = int(max_batch_bytes)
@@ -198,7 +215,8 @@ def illumina(obj, out_prefix, n_reads, read_length, paired, frag_mean=400, frag_
              ins_prob2=0.00015, del_prob2=0.00023, frag_len_min=None, frag_len_max=None, haplotype_probs=None,
              barcodes=None, prob_dup=0.02, sep_files=False, compress=False, comp_method="bgzip", n_threads=1,
              read_pool_size=1000, show_progress=False, overwrite=False,
-             seed=None, seed_words=None, device=0, lane_begin=0, lane_end=0, max_batch_bytes=0, _session=False):
+             seed=None, seed_words=None, device=0, lane_begin=0, lane_end=0, max_batch_bytes=0, _session=False,
+             seed_fn=None, abort_flag=None):
     """Create and write Illumina reads (R/hts_illumina.R:593-732).
 
     With ``_session=True`` nothing is written: the opened `IlluminaSession` is returned instead
@@ -244,16 +262,16 @@ def illumina(obj, out_prefix, n_reads, read_length, paired, frag_mean=400, frag_
     prof1 = read_profile(profile1, seq_sys, read_length, 1)
     prof2 = read_profile(profile2, seq_sys, read_length, 2) if paired else None
 
-    if seed_words is None:
+    if seed_words is None and seed_fn is None:
         if seed is None:
-            raise ValueError("give `seed` (SplitMix64 seed for the 32-bit sub-seed words) or `seed_words`")
+            raise ValueError("give `seed` (SplitMix64 seed for the 32-bit sub-seed words), `seed_words` or `seed_fn`")
         budget = illumina_ref_seed_budget(n_threads) if is_ref else obj.seed_budget(n_threads)
         seed_words = _seed_words(seed, budget)
 
     args, keep = make_args(out_prefix, n_reads, paired, matepair, prof1, prof2, ins_prob1, del_prob1, ins_prob2,
                            del_prob2, frag_len_shape, frag_len_scale, frag_len_min, frag_len_max, barcodes, prob_dup,
                            n_threads, read_pool_size, seed_words, compress, comp_method, sep_files, haplotype_probs,
-                           lane_begin, lane_end, device, max_batch_bytes)
+                           lane_begin, lane_end, device, max_batch_bytes, seed_fn, abort_flag)
     L = _abi.lib()
     if is_ref:
         view, keep2 = obj._view()

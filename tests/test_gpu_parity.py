@@ -200,3 +200,31 @@ def test_unsupported_inputs_fail_loudly(ja):
         ja.illumina(g, None, 100, 150, True, n_threads=2, seed_words=words, frag_mean=100, frag_sd=200, _session=True)
     with pytest.raises(ja.JackalopeHipError, match="seed"):
         ja.illumina(g, None, 100, 150, True, n_threads=4, seed_words=words[:8], _session=True)
+
+
+def test_seed_callback_and_abort_flag(ja, O):
+    """The two hooks the Rcpp shim relies on: seeds pulled through a callback (Rcpp::runif there), eight words per
+    request in the reference's order, and the abort flag (Progress::check_abort) polled between batches."""
+    g = ja.synthetic_genome([50_000, 7_000], seed=18)
+    T, n = 12, 2400
+    words = ja.seed_words(21, 16 * T)
+    want1, want2, _, used = run_hip(ja, g, (None, None), 150, words, n, T, job())
+    calls = []
+
+    def next8():
+        k = len(calls)
+        calls.append(k)
+        return words[8 * k:8 * k + 8]
+    with ja.illumina(g, None, n, 150, True, n_threads=T, seed_fn=next8, _session=True) as s:
+        s.generate()
+        assert (s.fetch(0), s.fetch(1)) == (want1, want2)
+        assert s.seed_words_used() == used == 8 * len(calls)
+    with pytest.raises(ja.JackalopeHipError, match="seed callback failed"):
+        ja.illumina(g, None, n, 150, True, n_threads=T, seed_fn=lambda: [1, 2, 3], _session=True)
+    flag = np.ones(1, dtype=np.int32)
+    with ja.illumina(g, None, n, 150, True, n_threads=T, seed_words=words, abort_flag=flag, _session=True) as s:
+        with pytest.raises(ja.JackalopeHipError, match="aborted"):
+            s.generate()
+        flag[0] = 0
+        s.generate()
+        assert s.fetch(0) == want1
