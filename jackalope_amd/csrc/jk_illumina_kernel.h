@@ -167,7 +167,11 @@ __device__ __forceinline__ uint32_t runif_index32(uint64_t x, uint32_t n) {
 }
 
 // code (T0 C1 A2 G3) -> ASCII
-__device__ __forceinline__ uint32_t base_char(uint32_t code) { return (0x47414354u >> (8u * code)) & 0xffu; }
+__device__ __forceinline__ uint32_t base_char(uint32_t code) {        // code 0..3
+    // byte `code` of "TCAG" by v_perm_b32 (selector bytes 1..3 = 0x0c: constant zero): two instructions instead of
+    // shift, shift, mask
+    return __builtin_amdgcn_perm(0u, 0x47414354u, code | 0x0c0c0c00u);
+}
 
 // tables either in LDS or global
 struct TabPtrs {
