@@ -398,11 +398,18 @@ pacbio_kernel(PacbioKernelParams P) {
             const uint8_t* const gseq = P.g.seq;
             const uint64_t chrom_off = P.g.chrom_off[HAP ? ci % P.g.n_chroms : ci];
             uint64_t gaddr = 0, gbuf = 0; uint32_t gcnt = 0;
+            // reverse strand: the chunk is byte-swapped and its base codes complemented when it is loaded (code ^ 2 for
+            // bytes 0..3 only: the flip is gated by bit 2 of each byte being clear, which also leaves 'N', 0xfc..0xff
+            // and every byte that could turn INTO 'N' alone -- a flip never changes bit 2)
+            auto rc8 = [](uint64_t v) -> uint64_t {
+                v = __builtin_bswap64(v);
+                return v ^ (((~v) >> 1) & 0x0202020202020202ULL);
+            };
             auto src_init = [&](uint64_t a0) {
                 const uint64_t ch = a0 & ~7ULL;
                 uint64_t v = *reinterpret_cast<const uint64_t*>(gseq + ch);
                 const uint32_t k = (uint32_t)a0 & 7u;
-                if (reverse) { v = __builtin_bswap64(v); gbuf = v >> (8u * (7u - k)); gcnt = k + 1; gaddr = ch - 8; }
+                if (reverse) { v = rc8(v); gbuf = v >> (8u * (7u - k)); gcnt = k + 1; gaddr = ch - 8; }
                 else { gbuf = v >> (8u * k); gcnt = 8u - k; gaddr = ch + 8; }
             };
             auto src_next = [&]() -> uint32_t {
@@ -410,7 +417,7 @@ pacbio_kernel(PacbioKernelParams P) {
                 gbuf >>= 8;
                 if (--gcnt == 0) {
                     uint64_t v = *reinterpret_cast<const uint64_t*>(gseq + gaddr);
-                    if (reverse) { v = __builtin_bswap64(v); gaddr -= 8; } else gaddr += 8;
+                    if (reverse) { v = rc8(v); gaddr -= 8; } else gaddr += 8;
                     gbuf = v; gcnt = 8;
                 }
                 return c;
@@ -481,7 +488,7 @@ pacbio_kernel(PacbioKernelParams P) {
                     const uint32_t c = src_next();
                     // character of read[p2 + k] as the reference sees it (cmp_map for the reverse strand)
                     const bool is_nt = c < 4u;
-                    const uint32_t nt = is_nt ? (reverse ? (c ^ 2u) : c) : 4u;
+                    const uint32_t nt = is_nt ? c : 4u;            // (already complemented on the reverse strand)
                     const uint32_t ch = is_nt ? base_char(nt) : (reverse ? (c == 'N' ? (uint32_t)'N' : 0u) : jk_decode_other(c));
                     const uint32_t b0bit = (lo >> k) & 1u, b1bit = (hi >> k) & 1u;
                     const bool is_ins = b0bit && !b1bit, is_del = !b0bit && b1bit, is_sub = b0bit && b1bit;
