@@ -12,8 +12,8 @@
 // contiguous pool region and stages its text in LDS, 128 bytes per lane, leaving as whole 128-byte lines.  Per read the reference makes two
 // passes over the read's positions: (1) one draw per position classifies it as plain / insertion /
 // deletion / substitution, (2) the bases are emitted with one more draw per insertion or
-// substitution.  Pass 1 stores 2 bits per position in a per-lane HBM scratch laid out
-// [word][lane] (32 positions per u64, lanes advance in lock-step so the stores coalesce); pass 2
+// substitution.  Pass 1 stores 2 bits per position (as two 32-bit planes of one u64 per 32 positions) in a
+// per-lane HBM scratch laid out [word][lane] (lanes advance in lock-step so the stores coalesce); pass 2
 // reads them back.  Everything that only depends on an integer (pass count, read length <= chi2_n[2])
 // comes from host-built tables, so the device needs exp/pow/log10/qnorm (jk_math2.h) but no nmath.
 #pragma once
@@ -97,16 +97,6 @@ __device__ __forceinline__ uint64_t cut_point(double c, bool* all) {
 // flushing on its own whenever its private line fills (the first version) put a ~50-instruction
 // divergent block into ~40 % of all loop iterations; synchronised, the block runs once per ~110.
 // ---------------------------------------------------------------------------------------------
-// bits 0, 2, 4, ... 62 of v packed into bits 0..31
-__device__ __forceinline__ uint64_t _pext_even(uint64_t v) {
-    v &= 0x5555555555555555ULL;
-    v = (v | (v >> 1)) & 0x3333333333333333ULL;
-    v = (v | (v >> 2)) & 0x0f0f0f0f0f0f0f0fULL;
-    v = (v | (v >> 4)) & 0x00ff00ff00ff00ffULL;
-    v = (v | (v >> 8)) & 0x0000ffff0000ffffULL;
-    v = (v | (v >> 16)) & 0x00000000ffffffffULL;
-    return v;
-}
 constexpr int PB_BLOCK = 256;
 struct RingStream {
     uint8_t* gp;       // global address of the first byte not yet flushed (16-byte aligned)
@@ -344,7 +334,7 @@ pacbio_kernel(PacbioKernelParams P) {
                 extra = extra + (ins_rec ? 1u : 0u) - (del_rec ? 1u : 0u);
                 cur += (ins_rec ? 1u : 0u) + (del ? 0u : 1u);
                 if (pos >= max_pos) { err |= JK_KERR_PB_TOO_LONG; break; }
-                word |= (uint64_t)type << (2u * (pos & 31u));
+                word |= ((uint64_t)(type & 1u) | ((uint64_t)(type >> 1) << 32)) << (pos & 31u);
                 pos++;
                 if ((pos & 31u) == 0) { evl[(size_t)((pos >> 5) - 1u) * ev_stride] = word; word = 0; }
             }
@@ -365,7 +355,8 @@ pacbio_kernel(PacbioKernelParams P) {
                     scan--;
                     uint64_t* wp = evl + (scan >> 5) * ev_stride;
                     const uint64_t wv = *wp;
-                    if (((wv >> (2u * (scan & 31u))) & 3u) == 2u) { *wp = wv & ~(3ULL << (2u * (scan & 31u))); break; }
+                    const uint32_t bit = (uint32_t)scan & 31u;         // deletion = code 2: plane 1 set, plane 0 clear
+                    if (((wv >> (32u + bit)) & 1ULL) && !((wv >> bit) & 1ULL)) { *wp = wv & ~(1ULL << (32u + bit)); break; }
                 }
                 n_del--; space--;
             }
@@ -445,7 +436,7 @@ pacbio_kernel(PacbioKernelParams P) {
             uint64_t cur2 = 0, p2 = 0;
             while (cur2 < L) {
                 const uint64_t evw = (p2 < pos) ? evl[(p2 >> 5) * ev_stride] : 0;
-                const uint32_t lo = (uint32_t)_pext_even(evw), hi = (uint32_t)_pext_even(evw >> 1);   // bit k: code bit 0 / 1 of position k
+                const uint32_t lo = (uint32_t)evw, hi = (uint32_t)(evw >> 32);        // bit k: code bit 0 / 1 of position k
                 const uint32_t insm = lo & ~hi, delm = hi & ~lo;
                 // smallest k in [0, 32] with cur2 + k + #ins(<k) - #del(<k) >= L (monotone in k): positions < k are processed
                 uint32_t kcut;
