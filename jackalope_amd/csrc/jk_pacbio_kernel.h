@@ -52,6 +52,7 @@ struct PacbioKernelParams {
     uint64_t* lane_made;
     uint64_t* ev;                 // [ev_words][n_lanes] 2-bit event codes
     uint32_t ev_words;
+    uint64_t* hist;               // [2 * PB_HIST][n_lanes]: what earlier reads left in the reference's `read` buffer
     uint32_t* err;
     // read lengths
     uint32_t use_lognormal;
@@ -98,6 +99,7 @@ __device__ __forceinline__ uint64_t cut_point(double c, bool* all) {
 // divergent block into ~40 % of all loop iterations; synchronised, the block runs once per ~110.
 // ---------------------------------------------------------------------------------------------
 constexpr int PB_BLOCK = 256;
+constexpr uint32_t PB_HIST = 16;      // depth of the per-lane history of buffer-covering reads (see pacbio_kernel)
 struct RingStream {
     uint8_t* gp;       // global address of the first byte not yet flushed (16-byte aligned)
     uint32_t* lds;     // this thread's slot: word w of the ring is lds[(w >> 2) * PB_BLOCK * 4 + (w & 3)]
@@ -195,6 +197,19 @@ pacbio_kernel(PacbioKernelParams P) {
 
     uint64_t L = 0, read_start = 0, chrom_len = 0;
     bool is_dup = false;
+    // The reference copies a read's `space` source bases into a std::string member that never shrinks
+    // (RefChrom::fill_read, src/ref_classes.h:102-116) and then walks read positions until the read has its
+    // length (src/hts_pacbio.cpp:381-400).  For a duplicate that lost deletions because it abuts the chromosome
+    // end (:277-285), or for a read as long as its chromosome, that walk can run a few positions past `space` and
+    // picks up what EARLIER reads of the same thread left in the buffer.  Those bytes are reproduced from a
+    // per-lane stack of the reads whose buffer content is still visible (strictly decreasing `space` from bottom
+    // to top: a new read hides every earlier one that was not longer): entry = {space | reverse << 32 |
+    // cell << 33, read_start}.  A position no remembered read covers is the string's terminating NUL if it
+    // equals the string's size, and lies outside the string otherwise (undefined in the reference, refused here).
+    uint32_t hdepth = 0;
+    uint64_t buf_size = 0;            // size of that string: the longest window so far (position == size reads its NUL)
+    uint64_t* const hl = P.hist + lane;
+    const size_t hstride = (size_t)P.n_lanes;
     while (made < quota) {
         if (!is_dup) {
             // chromosome / cell.  Reference genome: first chromosome with a non-zero quota; the quota is never
@@ -207,6 +222,7 @@ pacbio_kernel(PacbioKernelParams P) {
                     cur_hap = hap;
                     ln_st.saved = 0.0; ln_st.saved_available = 0;
                     chi_st.saved = 0.0; chi_st.saved_available = 0;
+                    hdepth = 0; buf_size = 0;               // ... and its own (empty) read buffer
                 }
             }
             chrom_len = HAP ? P.h.cell_size[ci] : P.g.chrom_len[ci];
@@ -470,17 +486,9 @@ pacbio_kernel(PacbioKernelParams P) {
                         res |= (uint64_t)(code & 3u) << (2u * k);
                     }
                 }
-                // the reference would read stale buffer bytes past the read's window here (only reachable when a
-                // read is as long as its chromosome); refuse instead of inventing bytes
-                if (p2 + kcut > space) { err |= JK_KERR_PB_SPACE; break; }
-                // bytes of position p2 + k: up to two, in the low bytes, with their count in bits 16..17
-                auto emit = [&](uint32_t k) -> uint32_t {
-                    if (HAP && p2 + k >= seg_end) seg_enter(p2 + k);
-                    const uint32_t c = src_next();
-                    // character of read[p2 + k] as the reference sees it (cmp_map for the reverse strand)
-                    const bool is_nt = c < 4u;
-                    const uint32_t nt = is_nt ? c : 4u;            // (already complemented on the reverse strand)
-                    const uint32_t ch = is_nt ? base_char(nt) : (reverse ? (c == 'N' ? (uint32_t)'N' : 0u) : jk_decode_other(c));
+                // bytes of a position whose buffer character is `ch` (code `nt` if it is one of TCAG): up to two, in the
+                // low bytes, with their count in bits 16..17
+                auto apply = [&](uint32_t k, uint32_t ch, bool is_nt, uint32_t nt) -> uint32_t {
                     const uint32_t b0bit = (lo >> k) & 1u, b1bit = (hi >> k) & 1u;
                     const bool is_ins = b0bit && !b1bit, is_del = !b0bit && b1bit, is_sub = b0bit && b1bit;
                     const uint32_t code = (uint32_t)(res >> (2u * k)) & 3u;
@@ -491,19 +499,63 @@ pacbio_kernel(PacbioKernelParams P) {
                     const uint32_t nb = is_del ? 0u : (is_ins ? 2u : 1u);
                     return (is_del ? 0u : (b0 | (is_ins ? (ins_ch << 8) : 0u))) | (nb << 16);
                 };
+                auto emit = [&](uint32_t k) -> uint32_t {
+                    if (HAP && p2 + k >= seg_end) seg_enter(p2 + k);
+                    const uint32_t c = src_next();
+                    // character of read[p2 + k] as the reference sees it (cmp_map for the reverse strand)
+                    const bool is_nt = c < 4u;
+                    const uint32_t nt = is_nt ? c : 4u;            // (already complemented on the reverse strand)
+                    const uint32_t ch = is_nt ? base_char(nt) : (reverse ? (c == 'N' ? (uint32_t)'N' : 0u) : jk_decode_other(c));
+                    return apply(k, ch, is_nt, nt);
+                };
+                // position past this read's window: the character an earlier read left in the buffer (rare)
+                auto emit_stale = [&](uint32_t k) -> uint32_t {
+                    const uint64_t q = p2 + k;
+                    uint32_t d = hdepth;
+                    uint64_t e0 = 0, e1 = 0;
+                    bool found = false;
+                    while (d > 0) {                      // newest first: the first one long enough wrote position q last
+                        d--;
+                        e0 = hl[(2 * d) * hstride]; e1 = hl[(2 * d + 1) * hstride];
+                        if ((e0 & 0xffffffffULL) > q) { found = true; break; }
+                    }
+                    if (!found) {
+                        // read[size()] is the string's terminator (defined); anything further is outside the string
+                        if (q == buf_size) return apply(k, 0u, false, 4u);
+                        err |= JK_KERR_PB_SPACE;
+                        return 1u << 16;
+                    }
+                    const uint64_t sp_j = e0 & 0xffffffffULL;
+                    const bool rev_j = (e0 >> 32) & 1ULL;
+                    const uint32_t cell_j = (uint32_t)(e0 >> 33);
+                    const uint64_t hpos = rev_j ? (e1 + sp_j - 1 - q) : (e1 + q);
+                    uint64_t addr;
+                    const uint64_t coff = P.g.chrom_off[HAP ? cell_j % P.g.n_chroms : cell_j];
+                    if (HAP) {
+                        int64_t m = hap_search(P.h, cell_j, hpos);
+                        addr = hap_resolve(P.h, coff, cell_j, m, hpos).addr;
+                    } else addr = coff + hpos;
+                    const uint32_t c0 = gseq[addr];
+                    const bool is_nt = c0 < 4u;
+                    const uint32_t nt = is_nt ? (rev_j ? (c0 ^ 2u) : c0) : 4u;
+                    const uint32_t ch = is_nt ? base_char(nt) : (rev_j ? (c0 == 'N' ? (uint32_t)'N' : 0u) : jk_decode_other(c0));
+                    return apply(k, ch, is_nt, nt);
+                };
+                const uint32_t kmain = space > p2 ? (uint32_t)(space - p2 < kcut ? space - p2 : kcut) : 0u;
+                if (space > buf_size) buf_size = space;       // fill_read grew the string before the walk
                 // two positions per ring check: they add at most 4 bytes to fewer than 4 pending ones, so one
                 // word at most leaves the shift register (lanes near the end of their read run fewer positions)
                 uint32_t k = 0;
-                for (; k + 2u <= kcut; k += 2u) {
+                for (; k + 2u <= kmain; k += 2u) {
                     if (__builtin_amdgcn_ballot_w64(o.pend >= 31u)) rs_flush(o);
                     const uint32_t r0 = emit(k), r1 = emit(k + 1u);
                     const uint32_t n0 = r0 >> 16, n1 = r1 >> 16;
                     rs_put2(o, (r0 & 0xffffu) | ((r1 & 0xffffu) << (8u * n0)), n0 + n1);
                     cur2 += n0 + n1;
                 }
-                if (k < kcut) {
+                for (; k < kcut; k++) {                  // at most one position of the window, then the stale ones
                     if (__builtin_amdgcn_ballot_w64(o.pend >= 31u)) rs_flush(o);
-                    const uint32_t r0 = emit(k);
+                    const uint32_t r0 = k < kmain ? emit(k) : emit_stale(k);
                     rs_put2(o, r0 & 0xffffu, r0 >> 16);
                     cur2 += r0 >> 16;
                 }
@@ -514,6 +566,18 @@ pacbio_kernel(PacbioKernelParams P) {
             rs_fill(o, qual_left, split_pos < L ? split_pos : L);
             rs_fill(o, qual_right, split_pos < L ? L - split_pos : 0);
             rs_put(o, '\n');
+            // this read's window now sits in the buffer: it hides every remembered read that was not longer
+            while (hdepth > 0 && (hl[(2 * (hdepth - 1)) * hstride] & 0xffffffffULL) <= space) hdepth--;
+            if (hdepth == PB_HIST) {                 // forget the oldest (longest) one; a position only it covered is refused
+                for (uint32_t d = 1; d < PB_HIST; d++) {
+                    hl[(2 * d - 2) * hstride] = hl[(2 * d) * hstride];
+                    hl[(2 * d - 1) * hstride] = hl[(2 * d + 1) * hstride];
+                }
+                hdepth--;
+            }
+            hl[(2 * hdepth) * hstride] = (space & 0xffffffffULL) | ((uint64_t)(reverse ? 1u : 0u) << 32) | ((uint64_t)ci << 33);
+            hl[(2 * hdepth + 1) * hstride] = read_start;
+            hdepth++;
         }
         if (HAP) ccnt = ccnt > 0 ? ccnt - 1 : 0;     // n_reads_vc[hap][chr]-- (one_read) / if > 0 (re_read)
 

@@ -33,7 +33,7 @@ struct jk_session {
     bool host_deflate = false; // comp_method "bgzip-host": BGZF blocks deflated by zlib on the host at level `compress`
     bool pacbio = false;
     PacbioKernelParams kpb{};
-    DevBuf d_len_thresh, d_len_alias, d_lens, d_thr_tab, d_pass_tab, d_ev2;
+    DevBuf d_len_thresh, d_len_alias, d_lens, d_thr_tab, d_pass_tab, d_ev2, d_pb_hist;
     uint32_t ev_words = 0;
     uint64_t nuc_base = 0;     // offset of the haplotypes' nucleotide blob inside d_seq
     double pool_scale = 1.25;  // PacBio: pool capacity relative to the expected bytes (grown on overflow)
