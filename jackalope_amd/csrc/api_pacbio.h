@@ -141,6 +141,9 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     P.ev = s.d_ev2.as<uint64_t>(); P.ev_words = s.ev_words;
     s.d_pb_hist.alloc((size_t)2 * PB_HIST * std::max<uint32_t>(max_lanes, 1) * 8);
     P.hist = s.d_pb_hist.as<uint64_t>();
+    // Outside the reference's `read` string its behaviour is undefined; by default such a read ends the run
+    // (JK_ERR_UNSUPPORTED).  Opt-in: treat the byte as NUL, which is what freshly allocated string capacity holds.
+    if (const char* e = std::getenv("JK_PB_UNDEFINED_AS_NUL")) P.undefined_as_nul = std::atoi(e) != 0;
     P.err = s.d_err.as<uint32_t>();
     P.len_thresh = s.d_len_thresh.as<uint64_t>(); P.len_alias = s.d_len_alias.as<uint32_t>(); P.lens = s.d_lens.as<uint64_t>();
     P.thr_tab = s.d_thr_tab.as<double>(); P.pass_tab = s.d_pass_tab.as<PassEntry>();

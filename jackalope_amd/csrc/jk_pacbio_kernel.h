@@ -53,6 +53,7 @@ struct PacbioKernelParams {
     uint64_t* ev;                 // [ev_words][n_lanes] 2-bit event codes
     uint32_t ev_words;
     uint64_t* hist;               // [2 * PB_HIST][n_lanes]: what earlier reads left in the reference's `read` buffer
+    uint32_t undefined_as_nul;    // JK_PB_UNDEFINED_AS_NUL=1: a position outside that buffer reads as NUL instead of ending the run
     uint32_t* err;
     // read lengths
     uint32_t use_lognormal;
@@ -521,7 +522,7 @@ pacbio_kernel(PacbioKernelParams P) {
                     }
                     if (!found) {
                         // read[size()] is the string's terminator (defined); anything further is outside the string
-                        if (q == buf_size) return apply(k, 0u, false, 4u);
+                        if (q == buf_size || P.undefined_as_nul) return apply(k, 0u, false, 4u);
                         err |= JK_KERR_PB_SPACE;
                         return 1u << 16;
                     }
