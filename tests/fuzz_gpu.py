@@ -116,13 +116,24 @@ def pacbio_case(ja, O, rng, case):
         pb["max_passes"] = int(rng.choice([1, 4, 20]))
     desc = "pacbio case %d: chroms=%s T=%d n=%d %s" % (case, sizes, T, n, pb)
     words = ja.seed_words(int(rng.integers(0, 2 ** 31)), 64 * T * 8 + 256)
+    hs = None
+    if rng.random() < 0.3:
+        hs = builder_haplotypes(ja, sizes, int(rng.choice([1, 2, 3])), int(rng.choice([10, 300])), seed=int(rng.integers(0, 10 ** 6)))
+        probs = [float(x) for x in rng.choice([0.5, 1.0, 2.0], size=hs.n_haps())]
+        desc += " haps=%d probs=%s" % (hs.n_haps(), probs)
     try:
-        h, reads, used_h = hip(ja, g, n, T, words, pb)
+        if hs is not None:
+            h, reads, used_h = hip(ja, hs, n, T, words, dict(pb, haplotype_probs=probs))
+        else:
+            h, reads, used_h = hip(ja, g, n, T, words, pb)
     except ja.JackalopeHipError as e:
         if e.code == 2:
             return "refused", desc + " -> " + str(e)
         raise AssertionError(desc + "\nunexpected error: %s" % e)
-    o, used_o, _ = O.pacbio_ref(g, pb, n_reads=n, n_threads=T, words=words)
+    if hs is not None:
+        o, used_o, _ = O.pacbio_hap(hs, pb, hap_probs=probs, n_reads=n, n_threads=T, words=words)
+    else:
+        o, used_o, _ = O.pacbio_ref(g, pb, n_reads=n, n_threads=T, words=words)
     assert used_h == used_o, desc + "\nseed words: HIP %d oracle %d" % (used_h, used_o)
     if h != o:
         raise AssertionError(desc + "\nFASTQ differs at byte %d:\nHIP    %r\noracle %r" % first_diff(h, o))
