@@ -140,6 +140,78 @@ def pacbio_case(ja, O, rng, case):
     return "ok", desc
 
 
+def genome_case(ja, O, rng, case):
+    n_chroms = int(rng.choice([1, 2, 5, 24, 100]))
+    len_mean = float(rng.choice([1, 7, 100, 2047, 2048, 5000, 60000]))
+    len_sd = float(rng.choice([0, 0, len_mean * 0.1, len_mean * 0.9]))
+    pi = rng.choice([0.0, 0.1, 1.0, 3.0], size=4)
+    if pi.sum() == 0:
+        pi[int(rng.integers(0, 4))] = 1.0
+    T = int(rng.choice([1, 1, 2, 7, 64]))
+    desc = "genome case %d: n=%d mean=%g sd=%g pi=%s T=%d" % (case, n_chroms, len_mean, len_sd, pi.tolist(), T)
+    words = ja.seed_words(int(rng.integers(0, 2 ** 31)), 8 * T)
+    want, used = O.create_genome(n_chroms, len_mean, len_sd, pi.tolist(), T, words)
+    g = ja.create_genome(n_chroms, len_mean, len_sd, pi.tolist(), T, seed_words=words)
+    assert g.seed_words_used() == used and g.sizes() == [len(c) for c in want], desc
+    for i, w in enumerate(want):
+        assert g.chrom(i).tobytes() == w, desc + " chromosome %d" % i
+    g.close()
+    return "ok", desc
+
+
+def fasta_case(ja, O, rng, case, tmp):
+    import gzip
+    n = int(rng.choice([1, 2, 9]))
+    width = int(rng.choice([1, 7, 60, 80, 4096, 100000]))
+    nl = b"\r\n" if rng.random() < 0.25 else b"\n"
+    alphabet = np.frombuffer(b"TCAGTCAGTCAGNtcagnRYKM-*", dtype=np.uint8)
+    fn = os.path.join(tmp, "f%d.fa" % case)
+    with open(fn, "wb") as f:
+        for i in range(n):
+            name = ("c%d" % i) + (" some text here" if rng.random() < 0.5 else "")
+            f.write(b">" + name.encode() + nl)
+            L = int(rng.choice([0, 1, 79, 80, 81, 4095, 4096, 4097, rng.integers(100, 200000)]))
+            seq = bytes(alphabet[rng.integers(0, alphabet.size, size=L)])
+            for a in range(0, L, width):
+                f.write(seq[a:a + width] + (nl if (a + width < L or rng.random() < 0.9) else b""))
+    files = [fn]
+    if rng.random() < 0.3:
+        gz = fn + ".gz"
+        open(gz, "wb").write(gzip.compress(open(fn, "rb").read()))
+        files = [gz]
+    cut = bool(rng.random() < 0.5)
+    desc = "fasta case %d: %d chromosomes, width %d, %s, cut_names=%s, %s" % (case, n, width, "CRLF" if nl != b"\n" else "LF", cut, files[0][-3:])
+    want_names, want = O.read_fasta(files, None, cut_names=cut)
+    g = ja.read_fasta(files, cut_names=cut)
+    assert [x.encode() for x in g.names] == want_names, desc
+    assert g.sizes() == [len(c) for c in want], desc
+    for i, w in enumerate(want):
+        assert g.chrom(i).tobytes() == w, desc + " chromosome %d" % i
+    g.close()
+    return "ok", desc
+
+
+def bgzf_case(ja, O, rng, case):
+    import gzip
+    n = int(rng.choice([0, 1, 63, 64, 65, 0xff00 - 1, 0xff00, 0xff00 + 1, rng.integers(1, 400000)]))
+    style = rng.choice(["fastq", "uniform", "skewed", "runs", "binary"])
+    if style == "fastq":
+        data = bytes(np.frombuffer(b"ACGTN\n@+IIIIFFF#", dtype=np.uint8)[rng.integers(0, 16, size=n)])
+    elif style == "uniform":
+        data = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+    elif style == "skewed":
+        data = np.minimum(rng.geometric(0.3, size=n), 255).astype(np.uint8).tobytes()
+    elif style == "runs":
+        data = np.repeat(rng.integers(0, 256, size=n // 50 + 1, dtype=np.uint8), 50)[:n].tobytes()
+    else:
+        data = (rng.integers(0, 4, size=n, dtype=np.uint8) * 85).tobytes()
+    desc = "bgzf case %d: %d bytes, %s" % (case, n, style)
+    comp = ja.bgzf_deflate(data).cpu().numpy().tobytes()
+    assert len(comp) <= ja.bgzf_bound(n), desc
+    assert gzip.decompress(comp) == data, desc
+    return "ok", desc
+
+
 def run(seconds, seed, kind, max_cases=None, verbose=True, first_case=0):
     import jackalope_amd as ja
     import oracle_lib as O
@@ -148,7 +220,16 @@ def run(seconds, seed, kind, max_cases=None, verbose=True, first_case=0):
     while time.time() - t0 < seconds and (max_cases is None or case < first_case + max_cases):
         rng = np.random.default_rng([seed, case])          # every case is reproducible on its own (--first-case N --cases 1)
         which = kind if kind != "all" else ("pacbio" if rng.random() < 0.25 else "illumina")
-        res, desc = (pacbio_case if which == "pacbio" else illumina_case)(ja, O, rng, case)
+        if which == "genome":
+            res, desc = genome_case(ja, O, rng, case)
+        elif which == "fasta":
+            import tempfile
+            with tempfile.TemporaryDirectory(prefix="jk_fuzz_") as tmp:
+                res, desc = fasta_case(ja, O, rng, case, tmp)
+        elif which == "bgzf":
+            res, desc = bgzf_case(ja, O, rng, case)
+        else:
+            res, desc = (pacbio_case if which == "pacbio" else illumina_case)(ja, O, rng, case)
         stats[res] += 1
         if verbose and (res == "refused" or case % 25 == 0):
             print("[%5.0fs] %s: %s" % (time.time() - t0, res, desc[:200]), flush=True)
@@ -160,7 +241,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--kind", choices=["illumina", "pacbio", "all"], default="all")
+    ap.add_argument("--kind", choices=["illumina", "pacbio", "genome", "fasta", "bgzf", "all"], default="all",
+                    help="all = illumina + pacbio; the genome-side kinds are run on their own")
     ap.add_argument("--first-case", type=int, default=0)
     ap.add_argument("--cases", type=int, default=None)
     a = ap.parse_args()
