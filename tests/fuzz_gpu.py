@@ -46,7 +46,11 @@ def random_genome(ja, rng):
 
 def illumina_case(ja, O, rng, case):
     g = random_genome(ja, rng)
-    read_length = int(rng.choice([36, 50, 75, 100, 125, 150, 150, 150]))
+    # sequencing system (built-in ART profile) and a read length it covers; None = the default for the length
+    systems = [(None, 150), (None, 150), ("GA1", 44), ("GA2", 75), ("NS50", 75), ("HS10", 100), ("HS20", 100), ("HS25", 150),
+               ("HSXn", 150), ("HSXt", 150), ("MSv1", 250), ("MSv3", 250)]
+    seq_sys, max_len = systems[int(rng.integers(0, len(systems)))]
+    read_length = int(rng.choice([x for x in (36, 44, 50, 75, 100, 125, 150, 150, 200, 250) if x <= max_len]))
     kind = rng.choice(["pe", "pe", "se", "mp"])
     frag_mean = float(rng.choice([read_length * 1.2, 300.0, 400.0, 900.0]))
     frag_sd = float(frag_mean / rng.choice([1.5, 4.0, 8.0]))
@@ -65,13 +69,13 @@ def illumina_case(ja, O, rng, case):
     ends = 1 if kind == "se" else 2
     n_reads = int(rng.integers(1, 40)) * T * ends // int(rng.choice([1, 2, 3])) + int(rng.integers(0, 3))
     n_reads = max(n_reads, ends)
-    desc = "illumina case %d: L=%d %s chroms=%s T=%d n=%d %s" % (case, read_length, kind, g.sizes(), T, n_reads,
+    desc = "illumina case %d: L=%d %s %s chroms=%s T=%d n=%d %s" % (case, read_length, seq_sys, kind, g.sizes(), T, n_reads,
                                                                  {k: v for k, v in j.items() if k not in ("paired", "matepair")})
     use_hap = rng.random() < 0.35 and min(g.sizes()) > 400
     words = ja.seed_words(int(rng.integers(0, 2 ** 31)), 64 * T * 8 + 256)
     paired = j["paired"] or j["matepair"]
-    p1 = ja.read_profile(None, None, read_length, 1)
-    p2 = ja.read_profile(None, None, read_length, 2) if paired else None
+    p1 = ja.read_profile(None, seq_sys, read_length, 1)
+    p2 = ja.read_profile(None, seq_sys, read_length, 2) if paired else None
     try:
         if use_hap:
             from test_gpu_hap import hip_hap, oracle_hap
@@ -81,11 +85,11 @@ def illumina_case(ja, O, rng, case):
                 probs[0] = 1.0
             desc += " haps=%d probs=%s" % (hs.n_haps(), probs)
             bcs = [j["barcode"]] * hs.n_haps()
-            h = hip_hap(ja, hs, read_length, words, n_reads, T, j, probs, bcs)
+            h = hip_hap(ja, hs, read_length, words, n_reads, T, j, probs, bcs, seq_sys=seq_sys)
             o = oracle_hap(O, hs, p1, p2, words, n_reads, T, j, probs, bcs)
             got, want, used_h, used_o = (h[0], h[1]), (o[0], o[1]), h[3], o[2]
         else:
-            h1, h2, _, used_h = run_hip(ja, g, (None, None), read_length, words, n_reads, T, j)
+            h1, h2, _, used_h = run_hip(ja, g, (None, None), read_length, words, n_reads, T, j, seq_sys=seq_sys)
             o1, o2, used_o = run_oracle(O, g, p1, p2, words, n_reads, T, j)
             got, want = (h1, h2), (o1, o2)
     except ja.JackalopeHipError as e:
