@@ -17,6 +17,12 @@
  *                      src/hts.h:323-500
  *   mt_seeds / seeded_pcg (R RNG contract)              jk_seed_source
  *                      src/pcg.h:37-85
+ *   make_hap_set, add_substitution / add_insertion /    jk_hap_builder_new, jk_add_substitution / _insertion /
+ *   add_deletion       src/ref_hap_access.cpp:127,816   _deletion, jk_hap_builder_view
+ *   FileBGZF / bgzip_file  src/io.h:150, src/hts.h:140  jk_bgzf_deflate (and comp_method "bgzip" of the sessions)
+ *   create_genome_cpp  src/create_sequences.cpp:151     jk_create_genome  (genome stays in device memory)
+ *   read_fasta_noind / read_fasta_ind                   jk_read_fasta
+ *                      src/io_fasta.cpp:153, :389
  *
  * Semantics kept from the reference: `n_threads` is the number of independent generator streams
  * ("lanes").  Lane t behaves exactly like OpenMP thread t of the reference: its own pcg64 seeded
