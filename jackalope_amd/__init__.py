@@ -5,7 +5,7 @@ include/jackalope_hip.h) and the host-side mirror of the reference's R-level int
 """
 from ._abi import JackalopeHipError, lib  # noqa: F401
 from .bgzf import bgzf_bound, bgzf_deflate  # noqa: F401
-from .genome import DeviceGenome, HapBuilder, HapSet, RefGenome, create_genome, read_fasta, synthetic_genome  # noqa: F401
+from .genome import DeviceGenome, FlatHapSet, HapBuilder, HapSet, RefGenome, create_genome, read_fasta, synthetic_genome  # noqa: F401
 from .illumina import illumina, IlluminaSession  # noqa: F401
 from .pacbio import pacbio  # noqa: F401
 from .profiles import read_profile, Profile  # noqa: F401

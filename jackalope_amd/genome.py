@@ -373,6 +373,79 @@ class HapBuilder:
         return HapSet(self.ref, cells, names)
 
 
+class FlatHapSet:
+    """Haplotypes held directly in the flat layout of ``jk_hap_set`` (numpy arrays): for tables with millions of
+    mutations, where per-mutation Python objects (``HapSet.cells``) are too slow.  Same read-side interface as
+    ``HapSet`` for illumina()/pacbio()."""
+
+    def __init__(self, ref, n_haps, chrom_size, n_mut, old_pos, new_pos, nuc_off, blob, names=None):
+        self.ref = ref
+        self._n_haps = int(n_haps)
+        self.chrom_size = np.ascontiguousarray(chrom_size, dtype=np.uint64)
+        self.n_mut = np.ascontiguousarray(n_mut, dtype=np.uint64)
+        self.old_pos = np.ascontiguousarray(old_pos, dtype=np.uint64)
+        self.new_pos = np.ascontiguousarray(new_pos, dtype=np.uint64)
+        self.nuc_off = np.ascontiguousarray(nuc_off, dtype=np.uint64)
+        self.blob = np.ascontiguousarray(np.concatenate([np.asarray(blob, dtype=np.uint8), np.zeros(1, dtype=np.uint8)]))
+        self.names = list(names) if names is not None else ["hap%d" % i for i in range(self._n_haps)]
+
+    def n_haps(self):
+        return self._n_haps
+
+    def hap_names(self):
+        return list(self.names)
+
+    seed_budget = HapSet.seed_budget
+
+    def _view(self):
+        rv, keep = self.ref._view()
+        names = (C.c_char_p * self._n_haps)(*[x.encode() for x in self.names])
+        v = _abi.HapSetView()
+        v.n_haps, v.n_chroms = self._n_haps, self.ref.n_chroms()
+        v.hap_names = names
+        v.ref = rv
+        p64 = C.POINTER(C.c_uint64)
+        v.chrom_size = self.chrom_size.ctypes.data_as(p64)
+        v.n_mut = self.n_mut.ctypes.data_as(p64)
+        v.old_pos = self.old_pos.ctypes.data_as(p64)
+        v.new_pos = self.new_pos.ctypes.data_as(p64)
+        v.nuc_off = self.nuc_off.ctypes.data_as(p64)
+        v.nuc_blob = self.blob.ctypes.data
+        return v, [keep, names, self]
+
+
+def random_haplotypes_flat(ref, n_haps, seed, sub_rate=1e-3, ins_rate=1e-4, del_rate=1e-4):
+    """Vectorised synthetic tables for genome-scale runs (BASELINE configs[2..3]): substitutions and 1-base
+    insertions / deletions at the given per-base rates, candidate sites at least 4 bases apart (never adjacent or
+    overlapping), in the reference's canonical representation."""
+    rng = np.random.default_rng(seed)
+    lut = np.frombuffer(b"TCAG", dtype=np.uint8)
+    total = sub_rate + ins_rate + del_rate
+    sizes, counts, ops, nps, lens, blobs = [], [], [], [], [], []
+    for h in range(n_haps):
+        for seq in ref.seqs:
+            n = int(seq.size)
+            k = int(n * total)
+            pos = np.unique(rng.integers(1, max(n - 2, 2), size=k) & ~np.int64(3)) if n > 8 else np.zeros(0, dtype=np.int64)
+            pos = pos[pos >= 1]
+            kind = rng.choice(3, size=pos.size, p=np.array([sub_rate, ins_rate, del_rate]) / total)
+            delta = np.where(kind == 1, 1, np.where(kind == 2, -1, 0)).astype(np.int64)
+            shift = np.concatenate([[0], np.cumsum(delta)[:-1]]) if pos.size else np.zeros(0, dtype=np.int64)
+            nlen = np.where(kind == 0, 1, np.where(kind == 1, 2, 0)).astype(np.int64)
+            off = np.concatenate([[0], np.cumsum(nlen)])
+            blob = np.zeros(int(off[-1]), dtype=np.uint8)
+            rnd = lut[rng.integers(0, 4, size=pos.size)]
+            sub = kind == 0
+            ins = kind == 1
+            blob[off[:-1][sub]] = rnd[sub]
+            blob[off[:-1][ins]] = seq[pos[ins]]
+            blob[off[:-1][ins] + 1] = rnd[ins]
+            sizes.append(n + int(delta.sum())); counts.append(pos.size)
+            ops.append(pos.astype(np.uint64)); nps.append((pos + shift).astype(np.uint64)); lens.append(nlen); blobs.append(blob)
+    nuc_off = np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.uint64) if lens else np.zeros(1, dtype=np.uint64)
+    return FlatHapSet(ref, n_haps, sizes, counts, np.concatenate(ops), np.concatenate(nps), nuc_off, np.concatenate(blobs))
+
+
 def random_haplotypes(ref, n_haps, seed, sub_rate=1e-3, ins_rate=1e-4, del_rate=1e-4, mean_indel=3.0):
     """Synthetic mutation tables in the reference's canonical representation (stand-in for
     haps_phylo()/create_haplotypes(), which are out of scope): substitutions, insertions and deletions

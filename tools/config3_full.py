@@ -1,0 +1,41 @@
+"""BASELINE configs[2] at full size on ONE MI355X: 3 Gbp reference (24 chromosomes of 125 Mbp, made on the device),
+4 haplotypes (substitutions 1e-3/bp, 1-base insertions and deletions 1e-4/bp each), 30x Illumina PE150 = 300 M
+pairs.  The whole FASTQ image (about 200 GB) stays in HBM; only counts and a few records are checked.
+
+    python tools/config3_full.py [--scale 1.0] [--lanes 2097152]
+"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import jackalope_amd as ja
+from jackalope_amd.genome import random_haplotypes_flat
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scale", type=float, default=1.0)
+ap.add_argument("--lanes", type=int, default=1 << 21)
+ap.add_argument("--haps", type=int, default=4)
+a = ap.parse_args()
+
+t = time.time()
+n_chroms, chrom_len = 24, int(125e6 * a.scale)
+dev = ja.create_genome(n_chroms, chrom_len, 0, seed_words=ja.seed_words(3, 8))
+ref = ja.RefGenome([dev.chrom(i) for i in range(n_chroms)], names=dev.names)
+dev.close()
+print("genome %.2f Gbp made on the device and fetched: %.1f s" % (n_chroms * chrom_len / 1e9, time.time() - t), flush=True)
+t = time.time()
+hs = random_haplotypes_flat(ref, a.haps, seed=31)
+print("%d haplotypes, %d mutations: %.1f s" % (a.haps, int(hs.n_mut.sum()), time.time() - t), flush=True)
+n_pairs = int(n_chroms * chrom_len * 30 / 300)
+words = ja.seed_words(12345, a.lanes * (16 + 16 * a.haps) + 64)
+t = time.time()
+s = ja.illumina(hs, None, 2 * n_pairs, 150, True, n_threads=a.lanes, seed_words=words, _session=True)
+print("open (host planning, uploads, %d lanes): %.1f s" % (a.lanes, time.time() - t), flush=True)
+with s:
+    for rep in range(2):
+        t = time.time(); s.generate(); dt = time.time() - t
+        sizes, reads = s.sizes(); tm = s.timing_ms()
+        print("generate: %d pairs, %.1f + %.1f GB FASTQ in %.3f s (generator kernels %.3f s, %d launches) -> %.1f M pairs/s"
+              % (reads // 2, sizes[0] / 1e9, sizes[1] / 1e9, dt, tm["generate_kernel"] / 1e3, s.n_batches(), reads / 2 / dt / 1e6), flush=True)
+    assert reads == 2 * n_pairs
+    import torch
+    print("HBM in use: %.1f GB" % ((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9))
