@@ -194,16 +194,16 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     std::vector<uint64_t> lane_cap(s.n_shard);
     for (uint64_t l = 0; l < s.n_shard; l++) lane_cap[l] = (lane_reads[l] / s.n_ends) * rec_max;
     const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, 1ULL << 18, lane_cap, lane_reads, lane_seeds, quotas);
-    s.d_info.upload(s.tables.info);
-    s.d_thresh.upload(s.tables.thresh);
-    s.d_quals.upload(s.tables.quals);
-    s.d_mm.upload(s.tables.mm_thresh);
+    const IlluminaPacked packed = pack_illumina_tables(s.tables);
+    s.d_info2.upload(packed.info2);
+    s.d_ent.upload(packed.ent);
+    s.d_mm2.upload(packed.mm2);
     s.evw_set = (size_t)s.n_ends * 4 * s.ev_words * std::max<uint32_t>(max_lanes, 1);      // u64 words per generator in flight
     s.d_evw.alloc(2 * s.evw_set * 8);
 
-    s.lds_bytes = (s.tables.thresh.size() + (s.tables.thresh.size() & 1)) * 8 + 256 * 8 + s.tables.info.size() * 4 + align_up(s.tables.quals.size() * 2, 16);
-    // haplotype runs add the per-lane segment table (4 segments x 12 bytes x 1024 lanes) after the tables
-    const size_t seg_bytes = s.hap ? (size_t)4 * 12 * JK_ILL_BLOCK : 0;
+    s.lds_bytes = packed.bytes();
+    // haplotype runs add the per-lane segment table (JK_HAP_SEGS segments x 12 bytes x 1024 lanes) after the tables
+    const size_t seg_bytes = s.hap ? (size_t)JK_HAP_SEGS * 12 * JK_ILL_BLOCK : 0;
     s.lds_tables = s.lds_bytes + seg_bytes <= 158 * 1024;
     s.lds_seg_off = s.lds_tables ? (uint32_t)align_up(s.lds_bytes, 16) : 0;
     s.lds_launch = (s.lds_tables ? align_up(s.lds_bytes, 16) : 0) + seg_bytes;
@@ -217,8 +217,7 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     P.g.n_chroms = s.n_chroms;
     P.evw = s.d_evw.as<uint64_t>();
     P.err = s.d_err.as<uint32_t>();
-    P.info = s.d_info.as<uint32_t>(); P.thresh = s.d_thresh.as<uint64_t>();
-    P.quals = s.d_quals.as<uint16_t>(); P.mm_thresh = s.d_mm.as<uint64_t>();
+    P.info2 = s.d_info2.as<uint32_t>(); P.ent = s.d_ent.as<uint32_t>(); P.mm2 = s.d_mm2.as<uint64_t>();
     P.n_info = (uint32_t)s.tables.info.size(); P.n_entries = (uint32_t)s.tables.thresh.size();
 
     P.lds_seg_off = s.lds_seg_off;

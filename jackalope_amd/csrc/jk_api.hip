@@ -53,6 +53,11 @@ extern "C" {
 
 const char* jk_last_error(void) { return g_last_error.c_str(); }
 const char* jk_version(void) { return "jackalope_hip 0.1 (gfx950)"; }
+#ifdef JK_TIMELINE
+int jk_debug_timeline(uint64_t* out, uint64_t n_words) {     // experiment builds only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(jk::g_timeline), n_words * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int jk_illumina_ref_open(const jk_ref_genome* genome, const jk_illumina_args* args, jk_session** out) {
     return guarded([&] {

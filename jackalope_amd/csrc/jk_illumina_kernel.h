@@ -31,6 +31,7 @@ namespace jk {
 
 constexpr int JK_MAX_BARCODE = 32;
 constexpr int JK_MAX_EVW = 16;         // 64-bit words of indel-event bitmaps per read end (positions < 1024)
+constexpr uint32_t JK_HAP_SEGS = 3;    // segments of a read window kept in the per-lane LDS table (haplotype runs)
 
 // error bits reported through IlluminaKernelParams::err
 enum : uint32_t {
@@ -94,9 +95,10 @@ struct IlluminaKernelParams {
     uint64_t th_dup; uint32_t dup_all;
     uint64_t pool_size;
     uint32_t bc_len; uint8_t barcode[JK_MAX_BARCODE];      // encoded like the genome
-    // tables (global copies; staged to LDS when LDS_TAB)
-    // info: [end][pos][nt] -> first entry (24 bits) | n entries (8 bits), 16 bytes per (end,pos)
-    const uint32_t* info; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm_thresh;
+    // tables (global copies; staged to LDS when LDS_TAB), see IlluminaPacked in jk_host.h:
+    //   mm2 [256] u64 by quality character; info2 [end][pos][nt] {first entry's byte offset in ent, n entries};
+    //   ent per alias entry {thresh lo, thresh hi, 8*char kept | 8*char of the alias << 16}
+    const uint32_t* info2; const uint32_t* ent; const uint64_t* mm2;
     uint32_t n_info, n_entries;
     uint32_t lds_seg_off;                                  // HAP: byte offset of the per-lane segment table in LDS
 };
@@ -173,10 +175,16 @@ __device__ __forceinline__ uint32_t base_char(uint32_t code) {        // code 0.
     return __builtin_amdgcn_perm(0u, 0x47414354u, code | 0x0c0c0c00u);
 }
 
-// tables either in LDS or global
+// tables either in LDS or global (byte pointers; layouts in IlluminaKernelParams)
 struct TabPtrs {
-    const uint32_t* info; const uint64_t* thresh; const uint16_t* quals; const uint64_t* mm;
+    const uint8_t* mm; const uint8_t* info2; const uint8_t* ent;
 };
+
+#ifdef JK_TIMELINE
+// experiment builds only (tools/timeline.sh): per wave {100 MHz wall clock at start, at end, HW_ID, XCC_ID}
+constexpr uint32_t JK_TIMELINE_WAVES = 1u << 15;
+__device__ uint64_t g_timeline[4 * JK_TIMELINE_WAVES];
+#endif
 
 struct HapSeg { uint64_t addr, begin, end; };   // haplotype positions [begin, end) lie contiguously at seq[addr + (pos - hpos)]
 
@@ -227,22 +235,59 @@ illumina_kernel(IlluminaKernelParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     TabPtrs T;
     if (LDS_TAB) {
-        uint64_t* s_thresh = reinterpret_cast<uint64_t*>(smem);
-        uint64_t* s_mm = s_thresh + P.n_entries;
-        uint32_t* s_info = reinterpret_cast<uint32_t*>(s_mm + 256 + (P.n_entries & 1u));   // keep 16-byte alignment
-        uint16_t* s_quals = reinterpret_cast<uint16_t*>(s_info + P.n_info);
-        for (uint32_t i = threadIdx.x; i < P.n_entries; i += blockDim.x) { s_thresh[i] = P.thresh[i]; s_quals[i] = P.quals[i]; }
-        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_mm[i] = P.mm_thresh[i];
-        for (uint32_t i = threadIdx.x; i < P.n_info; i += blockDim.x) s_info[i] = P.info[i];
+        // mm2 first: the kernel declares no static LDS, so its entries sit at LDS address 8*char
+        uint32_t* s_mm = reinterpret_cast<uint32_t*>(smem);
+        uint32_t* s_info = s_mm + 512;
+        uint32_t* s_ent = s_info + 2u * P.n_info;
+        const uint32_t* g_mm = reinterpret_cast<const uint32_t*>(P.mm2);
+        for (uint32_t i = threadIdx.x; i < 512u; i += blockDim.x) s_mm[i] = g_mm[i];
+        for (uint32_t i = threadIdx.x; i < 2u * P.n_info; i += blockDim.x) s_info[i] = P.info2[i];
+        for (uint32_t i = threadIdx.x; i < 3u * P.n_entries; i += blockDim.x) s_ent[i] = P.ent[i];
         __syncthreads();
-        T.info = s_info; T.thresh = s_thresh; T.quals = s_quals; T.mm = s_mm;
+        T.mm = smem; T.info2 = smem + 2048; T.ent = smem + 2048 + 8u * P.n_info;
     } else {
-        T.info = P.info; T.thresh = P.thresh; T.quals = P.quals; T.mm = P.mm_thresh;
+        T.mm = reinterpret_cast<const uint8_t*>(P.mm2); T.info2 = reinterpret_cast<const uint8_t*>(P.info2);
+        T.ent = reinterpret_cast<const uint8_t*>(P.ent);
     }
 
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= P.n_lanes) return;
 
+#ifdef JK_TIMELINE
+    const uint64_t tl_t0 = wall_clock64();
+#endif
+#ifdef JK_PRIO_BALANCE
+    // progress of the (up to 4) waves of this workgroup that share a SIMD, see bal_tick below
+    __shared__ uint32_t s_prog[16];
+    __shared__ uint32_t s_slots[4];
+    if (threadIdx.x < 16) s_prog[threadIdx.x] = 0xffffffffu;
+    if (threadIdx.x < 4) s_slots[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t bal_simd = (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4)) & 3u;     // HW_ID[5:4]
+    uint32_t bal_k = 0;
+    if ((threadIdx.x & 63u) == 0) bal_k = atomicAdd(&s_slots[bal_simd], 1u);
+    bal_k = __builtin_amdgcn_readfirstlane(bal_k);
+    const bool bal_on = bal_k < 4u;
+    uint32_t bal_prog = 0, bal_it = 0;
+    auto bal_tick = [&]() {
+        if (!bal_on) return;
+        bal_prog++;
+        s_prog[bal_simd * 4u + bal_k] = bal_prog;
+        const uint4 pr = *reinterpret_cast<const uint4*>(&s_prog[bal_simd * 4u]);
+        // waves that are ahead of this one (finished or absent ones read 0xffffffff: a constant offset)
+        uint32_t ahead = (pr.x > bal_prog) + (pr.y > bal_prog) + (pr.z > bal_prog) + (pr.w > bal_prog);
+        ahead = __builtin_amdgcn_readfirstlane(ahead);
+        const uint32_t present = __builtin_amdgcn_readfirstlane((pr.x != 0xffffffffu) + (pr.y != 0xffffffffu) + (pr.z != 0xffffffffu) + (pr.w != 0xffffffffu));
+        const uint32_t rank = ahead - (4u - present);           // 0 = leader .. 3 = last
+        if (rank == 0) __builtin_amdgcn_s_setprio(0);
+        else if (rank == 1) __builtin_amdgcn_s_setprio(1);
+        else if (rank == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    };
+#define JK_BAL_STEP() do { if ((++bal_it & 15u) == 0) bal_tick(); } while (0)
+#else
+#define JK_BAL_STEP() do { } while (0)
+#endif
     LaneRng rng;
     rng.e = jk_pcg_seed(P.seeds + (size_t)lane * 8);
     jk_gamma_state gst; gst.saved = 0.0; gst.saved_available = 0;
@@ -315,6 +360,7 @@ illumina_kernel(IlluminaKernelParams P) {
             const uint64_t thm = P.th_match[r], thd = P.th_del[r];
             const bool nm = P.never_match[r], nd = P.never_del[r];
             while (len_now < L && frag_pos < fl32) {
+                JK_BAL_STEP();
                 const uint64_t x = rng();
                 if (!nm && x >= thm) {
                     len_now++;
@@ -397,97 +443,77 @@ illumina_kernel(IlluminaKernelParams P) {
             os_put(oq, '\n'); os_put(oq, '+'); os_put(oq, '\n');
 
             // ---- bases + qualities (fill_read / rev_comp / fill_read_qual).
-            // Source position pp of the pre-indel read: pp < bc -> barcode; else forward
-            // chrom[start + pp - bc], reverse: complement of chrom[start + sp - 1 - pp].  The reference
-            // bytes are consumed low byte first from an 8-byte register chunk; for the reverse strand
-            // the chunk is byte-swapped and complemented when it is loaded.
+            // Source position pp of the pre-indel read: pp < bc -> barcode; else forward chrom[start + pp - bc],
+            // reverse: complement of chrom[start + sp - 1 - pp]; in both cases one byte of the encoded buffer at
+            // A + pp (forward) or A - pp (reverse), A being fixed per read end (per segment for haplotypes).
+            //
+            // The loop runs in two gears, chosen wave-uniformly:
+            //  * quads: when every lane has at least 4 (8) plain TCAG source bases ahead -- no barcode, indel event,
+            //    segment boundary, 'N' or read end in reach -- each lane loads its next 4 (8) source bytes with one
+            //    UNALIGNED load (so all lanes refill in the same iteration, whatever their alignment), turns them
+            //    into read order with v_perm (byte swap + complement for the reverse strand), maps the four codes of
+            //    a word to ASCII with one more v_perm, and runs four unrolled copies of the quality/mismatch step
+            //    with compile-time shifts;
+            //  * single bases, the general path (barcodes, indels, 'N', segment changes, uneven read lengths), until
+            //    the output position is a multiple of 4 again and no lane needs it.
             const uint8_t* const gseq = P.g.seq;
-            // (HAP: the chromosome's offset is only needed when a segment is entered; it is re-read there
-            // instead of being carried through the per-base loop)
-            const uint64_t chrom_off = HAP ? 0 : P.g.chrom_off[ci];
             const uint8_t* const bcode = HAP ? P.h.bc_blob + (size_t)cur_hap * JK_MAX_BARCODE : P.barcode;
-            uint64_t gaddr = 0;      // byte address (index into gseq) of the NEXT chunk to load
-            uint64_t gbuf = 0; uint32_t gcnt = 0;
-            auto src_init = [&](uint64_t a0) {      // position the reader on byte a0, moving down if reverse
-                const uint64_t ch = a0 & ~7ULL;
-                uint64_t v = *reinterpret_cast<const uint64_t*>(gseq + ch);
-                const uint32_t k = (uint32_t)a0 & 7u;
-                if (reverse) {
-                    v = __builtin_bswap64(v);
-                    v ^= ((~v) >> 1) & 0x0202020202020202ULL;       // codes 0..3: ^2 (T<->A, C<->G); 4 stays
-                    gbuf = v >> (8u * (7u - k)); gcnt = k + 1; gaddr = ch - 8;
-                } else {
-                    gbuf = v >> (8u * k); gcnt = 8u - k; gaddr = ch + 8;
-                }
-            };
+            uint64_t A = 0;
             // HAP: the read is served segment by segment (reference runs and mutation bytes);
             // seg_end_pp = first source position that is NOT in the current segment.  The segments of the
             // read's window are resolved ONCE here, before the per-base loop, into a small per-lane table in
-            // LDS (start position, buffer address; up to HAP_SEGS of them): a boundary met inside the loop then
-            // costs two LDS reads instead of a chain of dependent table loads from HBM -- with 64 lanes some
-            // lane meets a boundary in ~15 % of all iterations at 1.2 mutations per kb.  Reads that cross more
+            // LDS (start position, A of the segment; up to JK_HAP_SEGS of them): a boundary met inside the loop then
+            // costs two LDS reads instead of a chain of dependent table loads from HBM.  Reads that cross more
             // segments than the table holds resolve the rest on the fly.
             uint32_t seg_end_pp = 0xffffffffu;
             uint32_t seg_state = 0;                 // current segment | segments in the table << 8 | first unresolved position << 16
-            constexpr uint32_t HAP_SEGS = 4, NO_POS = 0xffffu;
+            constexpr uint32_t NO_POS = 0xffffu;
             uint32_t* const s_seg = HAP ? reinterpret_cast<uint32_t*>(smem + P.lds_seg_off) + threadIdx.x : nullptr;
             auto seg_hpos = [&](uint32_t pp) -> uint64_t { return reverse ? (start + sp - 1 - pp) : (start + pp - bc); };
-            auto seg_enter = [&](uint32_t pp) {     // pp >= bc; pp is the first position of the next segment
-                if (HAP) {
-                    const uint32_t cur = (seg_state & 0xffu) + 1u, n = (seg_state >> 8) & 0xffu, over = seg_state >> 16;
-                    if (cur < n) {
-                        const uint32_t* e = s_seg + 3u * cur * BLOCK;
-                        src_init(((uint64_t)e[2 * BLOCK] << 32) | e[BLOCK]);
-                        seg_end_pp = cur + 1u < n ? e[3 * BLOCK] : (over != NO_POS ? over : 0xffffffffu);
-                        seg_state = (seg_state & ~0xffu) | cur;
-                    } else {                        // beyond the table (rare): resolve from scratch
-                        const uint64_t hpos = seg_hpos(pp);
-                        int32_t m = (int32_t)hap_search(P.h, ci, hpos);
-                        const HapSeg sg = hap_resolve(P.h, P.g.chrom_off[ci % P.g.n_chroms], ci, m, hpos);
-                        src_init(sg.addr);
-                        const uint64_t avail = reverse ? (hpos - sg.begin + 1) : (sg.end - hpos);
-                        seg_end_pp = avail >= (uint64_t)(0xffffffffu - pp) ? 0xffffffffu : pp + (uint32_t)avail;
-                    }
-                } else {
-                    src_init(chrom_off + seg_hpos(pp));
+            auto seg_A = [&](uint64_t addr, uint32_t pp) -> uint64_t { return reverse ? addr + pp : addr - pp; };
+            auto seg_enter = [&](uint32_t pp) {     // HAP only; pp >= seg_end_pp: move to the next segment
+                const uint32_t cur = (seg_state & 0xffu) + 1u, n = (seg_state >> 8) & 0xffu, over = seg_state >> 16;
+                if (cur < n) {
+                    const uint32_t* e = s_seg + 3u * cur * BLOCK;
+                    A = ((uint64_t)e[2 * BLOCK] << 32) | e[BLOCK];
+                    seg_end_pp = cur + 1u < n ? e[3 * BLOCK] : (over != NO_POS ? over : 0xffffffffu);
+                    seg_state = (seg_state & ~0xffu) | cur;
+                } else {                            // beyond the table (rare): resolve from scratch
+                    const uint64_t hpos = seg_hpos(pp);
+                    int32_t m = (int32_t)hap_search(P.h, ci, hpos);
+                    const HapSeg sg = hap_resolve(P.h, P.g.chrom_off[ci % P.g.n_chroms], ci, m, hpos);
+                    A = seg_A(sg.addr, pp);
+                    const uint64_t avail = reverse ? (hpos - sg.begin + 1) : (sg.end - hpos);
+                    seg_end_pp = avail >= (uint64_t)(0xffffffffu - pp) ? 0xffffffffu : pp + (uint32_t)avail;
                 }
             };
             if (HAP) {
                 int32_t m = (int32_t)hap_search(P.h, ci, seg_hpos(bc));      // (a cell holds fewer than 2^31 mutations: checked at upload)
                 const uint64_t coff = P.g.chrom_off[ci % P.g.n_chroms];
                 uint32_t q = bc, n = 0;
-                while (q < sp && n < HAP_SEGS) {
+                while (q < sp && n < JK_HAP_SEGS) {
                     const uint64_t hpos = seg_hpos(q);
                     const HapSeg sg = hap_resolve(P.h, coff, ci, m, hpos);
+                    const uint64_t a = seg_A(sg.addr, q);
                     uint32_t* e = s_seg + 3u * n * BLOCK;
-                    e[0] = q; e[BLOCK] = (uint32_t)sg.addr; e[2 * BLOCK] = (uint32_t)(sg.addr >> 32);
+                    e[0] = q; e[BLOCK] = (uint32_t)a; e[2 * BLOCK] = (uint32_t)(a >> 32);
                     n++;
                     const uint64_t avail = reverse ? (hpos - sg.begin + 1) : (sg.end - hpos);
                     q = avail >= (uint64_t)(sp - q) ? sp : q + (uint32_t)avail;
                 }
                 seg_state = (n << 8) | ((q < sp ? q : NO_POS) << 16);
                 if (n) {
-                    src_init(((uint64_t)s_seg[2 * BLOCK] << 32) | s_seg[BLOCK]);
+                    A = ((uint64_t)s_seg[2 * BLOCK] << 32) | s_seg[BLOCK];
                     seg_end_pp = n > 1u ? s_seg[3 * BLOCK] : (q < sp ? q : 0xffffffffu);
                 }
-            } else if (sp > bc) seg_enter(bc);
-            auto src_next = [&]() -> uint32_t {    // next base of the current segment
-                const uint32_t c = (uint32_t)gbuf & 0xffu;
-                gbuf >>= 8;
-                if (--gcnt == 0) {
-                    uint64_t v = *reinterpret_cast<const uint64_t*>(gseq + gaddr);
-                    if (reverse) {
-                        v = __builtin_bswap64(v);
-                        v ^= ((~v) >> 1) & 0x0202020202020202ULL;
-                        gaddr -= 8;
-                    } else gaddr += 8;
-                    gbuf = v; gcnt = 8;
-                }
+            } else {
+                A = P.g.chrom_off[ci] + (reverse ? start + sp - 1 : start - bc);
+            }
+            auto src_byte = [&](uint32_t pp) -> uint32_t {     // general path: one source base (pp >= bc)
+                if (HAP) { while (pp >= seg_end_pp) seg_enter(pp); }
+                uint32_t c = gseq[reverse ? A - pp : A + pp];
+                if (reverse) c ^= ((~c) >> 1) & 2u;                 // codes 0..3: ^2 (T<->A, C<->G); others stay non-TCAG
                 return c;
-            };
-            auto src_take = [&](uint32_t pp) -> uint32_t {     // slow-path form: may have to change segment first
-                if (HAP && pp >= seg_end_pp) seg_enter(pp);
-                return src_next();
             };
             // first position of (ins|del) at or after pp, or "none"
             auto next_event = [&](uint32_t pp) -> uint32_t {
@@ -499,28 +525,106 @@ illumina_kernel(IlluminaKernelParams P) {
                 }
                 return 0xffffffffu;
             };
-
-            uint32_t pp = 0;
-            // `nes`: the next source position that needs the slow path (barcode, deletion, insertion);
-            // 0 forces it for the next base (pending inserted base).
+            // `nes`: the next source position that needs the general path (barcode, deletion, insertion, segment
+            // change); 0 forces it for the next base (pending inserted base).
             auto next_slow = [&](uint32_t pp) -> uint32_t {
                 uint32_t e = ev_any ? next_event(pp) : 0xffffffffu;
                 return (HAP && seg_end_pp < e) ? seg_end_pp : e;
             };
+
+            uint32_t pp = 0, op = 0;
             uint32_t nes = bc ? 0u : next_slow(0);
             bool pending = false; uint32_t pend_base = 0;
-            const uint32_t info_base = i * L;
-            // the 4 bytes of a quad of bases / qualities are gathered with wave-uniform shifts and merged
-            // into the streams' accumulators once per quad (the lane's phase o.cnt / oq.cnt is < 4 and
-            // does not change inside the loop)
-            uint32_t grp_b = 0, grp_q = 0;
+            // Output: the lane's phase in its 4-byte words (o.cnt / oq.cnt pending bytes, < 4) does not change while
+            // whole quads are appended, so a quad is merged with one 64-bit shift and leaves as one word per stream,
+            // stored by every lane of the wave in the same instruction.
             const uint32_t sh_b = 8u * o.cnt, sh_q = 8u * oq.cnt;
-            for (uint32_t op = 0; op < n_out; op++) {
+            uint32_t acc_b = (uint32_t)o.acc, acc_q = (uint32_t)oq.acc;
+            uint8_t* wpb = o.wp; uint8_t* wpq = oq.wp;
+            auto put_quad = [&](uint32_t gb, uint32_t gq) {
+                const uint64_t tb = (uint64_t)gb << sh_b, tq = (uint64_t)gq << sh_q;
+                *reinterpret_cast<uint32_t*>(wpb) = acc_b | (uint32_t)tb; acc_b = (uint32_t)(tb >> 32); wpb += TILE_ROW;
+                *reinterpret_cast<uint32_t*>(wpq) = acc_q | (uint32_t)tq; acc_q = (uint32_t)(tq >> 32); wpq += TILE_ROW;
+            };
+            // one quality + mismatch step (IlluminaQualityError::fill_read_qual, hts_illumina.h:243-256) for a TCAG
+            // base with code c (c8 = 8*c) at output position `opos`: returns 8 * quality character, sets `mism`
+            auto qual_step = [&](uint32_t c8, uint32_t opos, bool& mism) -> uint32_t {
+                const uint32_t* ip = reinterpret_cast<const uint32_t*>(T.info2 + (size_t)(i * L + opos) * 32u + c8);
+                const uint32_t ent_off = ip[0], nq = ip[1];
+                const uint64_t x1 = rng();
+                // (uint64)(runif_01 * nq), src/alias_sampler.h:55: hi32(xh*nq + B) with B = hi32((xl+1)*nq) <= nq <= 255;
+                // B can only matter when the low word of xh*nq is within 256 of wrapping (2^-24 per draw)
+                const uint64_t pr = (uint64_t)(uint32_t)(x1 >> 32) * nq;
+                uint32_t idx = (uint32_t)(pr >> 32);
+                if (__builtin_amdgcn_ballot_w64((uint32_t)pr >= 0xffffff00u) != 0) {
+                    asm volatile("" ::: "memory");
+                    if ((uint32_t)pr >= 0xffffff00u) idx = runif_index32(x1, nq);
+                }
+                const uint32_t* ep = reinterpret_cast<const uint32_t*>(T.ent + ent_off + idx * 12u);
+                const uint64_t th = ((uint64_t)ep[1] << 32) | ep[0];
+                const uint32_t qp = ep[2];
+                const uint64_t x2 = rng();
+                const uint64_t x3 = rng();
+                const uint32_t ch8 = (x2 < th) ? (qp & 0xffffu) : (qp >> 16);
+                const uint64_t mmth = *reinterpret_cast<const uint64_t*>(T.mm + ch8);
+                mism = x3 < mmth;
+                return ch8;
+            };
+            // mm_nucleos = {"CAG","TAG","TCG","TCA"} (src/hts.h:46): the m-th base that is not c
+            auto mismatch_char = [&](uint32_t c) -> uint32_t {
+                const uint32_t m = runif_index32(rng(), 3);
+                return (m < 3u) ? base_char(m + (m >= c ? 1u : 0u)) : 0u;
+            };
+            uint32_t grp_b = 0, grp_q = 0;          // the quad being filled by the general path
+            const uint32_t rsel = reverse ? 0x04050607u : 0x03020100u;      // v_perm selectors: read order of a chunk
+            const uint32_t rcm = reverse ? 0x02020202u : 0u;                // complement of codes 0..3
+            while (op < n_out) {
+                // ---- gear choice (wave-uniform)
+                uint32_t nquads = 0;
+                if ((op & 3u) == 0) {
+                    const uint32_t room = pending ? 0u : (nes - pp < n_out - op ? nes - pp : n_out - op);    // pp <= nes unless pending
+                    if (__builtin_amdgcn_ballot_w64(room < 4u) == 0)
+                        nquads = __builtin_amdgcn_ballot_w64(room < 8u) == 0 ? 2u : 1u;
+                }
+                uint32_t wlo = 0, whi = 0;
+                if (nquads == 2u) {
+                    uint32_t v[2];
+                    __builtin_memcpy(v, gseq + (reverse ? A - pp - 7u : A + pp), 8);
+                    if (__builtin_amdgcn_ballot_w64(((v[0] | v[1]) & 0xfcfcfcfcu) != 0) == 0) {
+                        wlo = __builtin_amdgcn_perm(v[1], v[0], rsel) ^ rcm;
+                        whi = __builtin_amdgcn_perm(v[1], v[0], rsel ^ 0x04040404u) ^ rcm;
+                    } else nquads = 0;
+                } else if (nquads == 1u) {
+                    uint32_t v;
+                    __builtin_memcpy(&v, gseq + (reverse ? A - pp - 3u : A + pp), 4);
+                    if (__builtin_amdgcn_ballot_w64((v & 0xfcfcfcfcu) != 0) == 0) wlo = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u) ^ rcm;
+                    else nquads = 0;
+                }
+                if (nquads) {
+                    for (uint32_t qd = 0; qd < nquads; qd++) {
+                        const uint32_t w = qd ? whi : wlo;
+                        uint32_t cw = __builtin_amdgcn_perm(0u, 0x47414354u, w);      // four codes -> "TCAG" characters
+                        const uint32_t w8 = w << 3;
+                        uint32_t gq = 0;
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; j++) {
+                            bool mism;
+                            const uint32_t ch8 = qual_step((w8 >> (8u * j)) & 0xffu, op + j, mism);
+                            gq |= j == 0 ? (ch8 >> 3) : (ch8 << (8u * j - 3u));
+                            if (mism) cw = (cw & ~(0xffu << (8u * j))) | (mismatch_char((w >> (8u * j)) & 3u) << (8u * j));
+                        }
+                        put_quad(cw, gq);
+                        op += 4;
+                    }
+                    pp += 4u * nquads;
+                    continue;
+                }
+                // ---- one base the general way
                 uint32_t c;
-                if (pp < nes) {                 // fast path: next reference base
-                    c = src_next();
+                if (pp < nes) {
+                    c = src_byte(pp);
                     pp++;
-                } else {                        // slow path (rare)
+                } else {
                     if (pending) {
                         c = pend_base; pending = false;
                     } else {
@@ -528,10 +632,9 @@ illumina_kernel(IlluminaKernelParams P) {
                             const uint32_t w = pp >> 6, bit = pp & 63u;
                             const bool deleted = w < W && ((ev >> (16 + w)) & 1u) && ((*evaddr(i, 1, w) >> bit) & 1ULL);
                             if (!deleted) break;
-                            if (pp >= bc) (void)src_take(pp);
                             pp++;
                         }
-                        c = (pp < bc) ? (uint32_t)bcode[pp] : src_take(pp);
+                        c = (pp < bc) ? (uint32_t)bcode[pp] : src_byte(pp);
                         const uint32_t w = pp >> 6, bit = pp & 63u;
                         if (w < W && ((ev >> w) & 1u) && ((*evaddr(i, 0, w) >> bit) & 1ULL)) {
                             pending = true;
@@ -539,26 +642,15 @@ illumina_kernel(IlluminaKernelParams P) {
                         }
                         pp++;
                     }
+                    if (HAP) { while (pp >= seg_end_pp && pp < sp) seg_enter(pp); }
                     nes = pending ? 0u : (pp < bc ? pp : next_slow(pp));
                 }
                 uint32_t q, ch;
                 if (c < 4u) {
-                    const uint32_t inf = T.info[(info_base + op) * 4u + c];
-                    const uint64_t x1 = rng();
-                    const uint32_t e = (inf & 0xffffffu) + runif_index32(x1, inf >> 24);
-                    const uint64_t th = T.thresh[e];
-                    const uint32_t qq = T.quals[e];
-                    const uint64_t x2 = rng();
-                    const uint64_t x3 = rng();
-                    const uint32_t k = (x2 < th) ? (qq & 0xffu) : (qq >> 8);
-                    const uint64_t mmth = T.mm[k];
-                    q = (k + 33u) & 0xffu;
+                    bool mism;
+                    q = qual_step(c << 3, op, mism) >> 3;
                     ch = base_char(c);
-                    if (x3 < mmth) {
-                        // mm_nucleos = {"CAG","TAG","TCG","TCA"} (src/hts.h:46): the m-th base that is not c
-                        const uint32_t m = runif_index32(rng(), 3);
-                        ch = (m < 3u) ? base_char(m + (m >= c ? 1u : 0u)) : 0u;
-                    }
+                    if (mism) ch = mismatch_char(c);
                 } else {
                     q = jk_n_qual(rng());
                     ch = 'N';
@@ -566,13 +658,11 @@ illumina_kernel(IlluminaKernelParams P) {
                 const uint32_t bsh = 8u * (op & 3u);       // wave-uniform
                 grp_b |= ch << bsh;
                 grp_q |= q << bsh;
-                if ((op & 3u) == 3u) {                     // wave-uniform: every lane stores one word per stream
-                    o.acc |= (uint64_t)grp_b << sh_b; o.cnt += 4u; os_store_word(o); grp_b = 0;
-                    oq.acc |= (uint64_t)grp_q << sh_q; oq.cnt += 4u; os_store_word(oq); grp_q = 0;
-                }
+                if ((op & 3u) == 3u) { put_quad(grp_b, grp_q); grp_b = 0; grp_q = 0; }
+                op++;
             }
-            o.acc |= (uint64_t)grp_b << sh_b; o.cnt += n_out & 3u;
-            oq.acc |= (uint64_t)grp_q << sh_q; oq.cnt += n_out & 3u;
+            o.acc = (uint64_t)acc_b | ((uint64_t)grp_b << sh_b); o.cnt += n_out & 3u; o.wp = wpb;
+            oq.acc = (uint64_t)acc_q | ((uint64_t)grp_q << sh_q); oq.cnt += n_out & 3u; oq.wp = wpq;
             o.pos += n_out; oq.pos += n_out;
             if (o.cnt >= 4u) os_store_word(o);
             if (oq.cnt >= 4u) os_store_word(oq);
@@ -599,6 +689,9 @@ illumina_kernel(IlluminaKernelParams P) {
         }
     }
 
+#ifdef JK_PRIO_BALANCE
+    if (bal_on) s_prog[bal_simd * 4u + bal_k] = 0xffffffffu;
+#endif
 #pragma unroll
     for (uint32_t i = 0; i < NE; i++) {
         os_flush(os[i]);
@@ -608,6 +701,13 @@ illumina_kernel(IlluminaKernelParams P) {
     }
     P.lane_made[lane] = made;
     if (err) atomicOr(P.err, err);
+#ifdef JK_TIMELINE
+    if ((threadIdx.x & 63u) == 0 && (lane >> 6) < JK_TIMELINE_WAVES) {
+        uint64_t* t = g_timeline + 4u * (lane >> 6);
+        t[0] = tl_t0; t[1] = wall_clock64();
+        t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); t[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
 }
 
 // ASCII -> code, in place (run once per uploaded buffer): T,C,A,G -> 0..3 (jlp::bases order, complement =

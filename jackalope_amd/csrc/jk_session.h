@@ -23,7 +23,7 @@ struct jk_session {
     uint32_t n_chroms = 0;
     // tables
     IlluminaTables tables;
-    DevBuf d_info, d_thresh, d_quals, d_mm;
+    DevBuf d_info2, d_ent, d_mm2;
     bool lds_tables = false;
     size_t lds_bytes = 0, lds_launch = 0, evw_set = 0;
     uint32_t lds_seg_off = 0;
