@@ -163,14 +163,27 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     s.d_chrom_reads.upload(quotas);
     s.d_pool_off.upload(pool_off);
     for (uint32_t e = 0; e < s.n_ends; e++) {
-        s.d_pool[0][e].alloc(max_pool + 64);
-        if (s.batches.size() > 1) s.d_pool[1][e].alloc(max_pool + 64);
+        s.d_pool[0][e].alloc(max_pool + 64 + CP_SLACK);
+        if (s.batches.size() > 1) s.d_pool[1][e].alloc(max_pool + 64 + CP_SLACK);
         s.d_out[e].alloc(out_cap + 64);
         s.d_lane_bytes[e].alloc(s.n_shard * 8);
         s.d_lane_off[e].alloc(s.n_shard * 8);
         s.d_base[e].alloc((s.batches.size() + 1) * 8);
     }
     s.d_lane_made.alloc(s.n_shard * 8);
+    // A third pool set takes the compaction of batch b off the critical path of generator b+2.  The generator fills
+    // the whole register file of every SIMD it runs on, so the compaction of batch b only gets going in the tail of
+    // generator b+1 (as its first waves retire) and ends after it; with two sets generator b+2 then waits.
+    s.n_pool_sets = 2;
+    for (uint32_t e = 0; e < s.n_ends; e++) s.d_pool[2][e].release();
+    if (s.batches.size() > 2) {
+        size_t free_b = 0, total_b = 0;
+        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        if (free_b > (max_pool + 64 + CP_SLACK) * s.n_ends + total_b / 16) {
+            for (uint32_t e = 0; e < s.n_ends; e++) s.d_pool[2][e].alloc(max_pool + 64 + CP_SLACK);
+            s.n_pool_sets = 3;
+        }
+    }
     s.d_block_sums.alloc((max_lanes / SCAN_BLOCK + 2) * 8);
     s.d_err.alloc(4);
     for (hipEvent_t e : s.events) (void)hipEventDestroy(e);
@@ -195,16 +208,15 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     for (uint64_t l = 0; l < s.n_shard; l++) lane_cap[l] = (lane_reads[l] / s.n_ends) * rec_max;
     const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, 1ULL << 18, lane_cap, lane_reads, lane_seeds, quotas);
     const IlluminaPacked packed = pack_illumina_tables(s.tables);
-    s.d_info2.upload(packed.info2);
-    s.d_ent.upload(packed.ent);
+    s.d_tab.upload(packed.tab);
     s.d_mm2.upload(packed.mm2);
     s.evw_set = (size_t)s.n_ends * 4 * s.ev_words * std::max<uint32_t>(max_lanes, 1);      // u64 words per generator in flight
     s.d_evw.alloc(2 * s.evw_set * 8);
 
-    s.lds_bytes = packed.bytes();
+    s.lds_bytes = packed.tab.size() * 4;        // dynamic LDS; the kernel keeps mm2 (2 KB) in static LDS on top
     // haplotype runs add the per-lane segment table (JK_HAP_SEGS segments x 12 bytes x 1024 lanes) after the tables
     const size_t seg_bytes = s.hap ? (size_t)JK_HAP_SEGS * 12 * JK_ILL_BLOCK : 0;
-    s.lds_tables = s.lds_bytes + seg_bytes <= 158 * 1024;
+    s.lds_tables = s.lds_bytes + seg_bytes <= 156 * 1024;
     s.lds_seg_off = s.lds_tables ? (uint32_t)align_up(s.lds_bytes, 16) : 0;
     s.lds_launch = (s.lds_tables ? align_up(s.lds_bytes, 16) : 0) + seg_bytes;
 
@@ -217,7 +229,7 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     P.g.n_chroms = s.n_chroms;
     P.evw = s.d_evw.as<uint64_t>();
     P.err = s.d_err.as<uint32_t>();
-    P.info2 = s.d_info2.as<uint32_t>(); P.ent = s.d_ent.as<uint32_t>(); P.mm2 = s.d_mm2.as<uint64_t>();
+    P.tab = s.d_tab.as<uint32_t>(); P.mm2 = s.d_mm2.as<uint64_t>();
     P.n_info = (uint32_t)s.tables.info.size(); P.n_entries = (uint32_t)s.tables.thresh.size();
 
     P.lds_seg_off = s.lds_seg_off;

@@ -14,7 +14,8 @@ static void launch_generate(jk_session& s) {
     for (size_t b = 0; b < s.batches.size(); b++) {
         if (s.abort_flag && *s.abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
         const Batch& B = s.batches[b];
-        const int pp = (int)(b & 1);       // ping-pong pool set
+        const int pp = (int)(b % (size_t)s.n_pool_sets);       // pool set in rotation
+        const size_t ns = (size_t)s.n_pool_sets;
         if (s.pacbio) {
             PacbioKernelParams Q = s.kpb;
             Q.n_lanes = B.n_lanes;
@@ -26,7 +27,7 @@ static void launch_generate(jk_session& s) {
             Q.pool = s.d_pool[pp][0].as<uint8_t>();
             Q.lane_bytes = s.d_lane_bytes[0].as<uint64_t>() + B.lane0;
             Q.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
-            if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));
+            if (b >= ns) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - ns], 0));
             JK_HIP(hipEventRecord(s.events[ev++], s.stream));
             const uint32_t pgrid = (B.n_lanes + 255) / 256;
             if (s.hap) hipLaunchKernelGGL((pacbio_kernel<true>), dim3(pgrid), dim3(256), 0, s.stream, Q);
@@ -61,7 +62,7 @@ static void launch_generate(jk_session& s) {
             P.lane_bytes[e] = e < s.n_ends ? s.d_lane_bytes[e].as<uint64_t>() + B.lane0 : nullptr;
         }
         P.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
-        P.evw = s.d_evw.as<uint64_t>() + (size_t)pp * s.evw_set;
+        P.evw = s.d_evw.as<uint64_t>() + (size_t)(b & 1) * s.evw_set;
         P.chrom_stride = (uint32_t)s.n_shard;
         // Two generators may be in flight (each has its own pool set and indel scratch): the next batch's
         // workgroups then take over CUs as the current batch's finish instead of waiting for its slowest one.
@@ -73,7 +74,7 @@ static void launch_generate(jk_session& s) {
         const uint32_t block = JK_ILL_BLOCK;
         const uint32_t grid = (B.n_lanes + block - 1) / block;
         // the pool set is free again once the compaction of batch b-2 has read it
-        if (b >= 2) JK_HIP(hipStreamWaitEvent(gs, s.cp_done[b - 2], 0));
+        if (b >= ns) JK_HIP(hipStreamWaitEvent(gs, s.cp_done[b - ns], 0));
         JK_HIP(hipEventRecord(s.events[ev++], gs));
 #define JK_LAUNCH(LDS, NE, HAP, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP>), dim3(grid), dim3(block), SH, gs, P)
         if (s.lds_tables) {

@@ -213,29 +213,29 @@ struct IlluminaTables {
 
 // The same tables in the form the kernel reads (one LDS/L2 access per step of a base, no unpacking arithmetic):
 //   mm2   [256] u64, indexed by the quality CHARACTER c = (q + 33) & 255 (what fill_read_qual emits): mm_thresh[q]
-//   info2 [end][pos][nt] {u32 byte offset of the first entry in ent, u32 number of entries}
-//   ent   per alias entry {u32 thresh lo, u32 thresh hi, u32 8*char if kept | 8*char of the alias << 16}
+//   tab   one blob of u32: info2 [end][pos][nt] {byte offset of the position's first alias entry in the blob,
+//         number of entries}, then per alias entry {thresh lo, thresh hi, 8*char if kept | 8*char of the alias << 16}
 //         (8*char = byte offset of the character's cut point in mm2)
 struct IlluminaPacked {
     std::vector<uint64_t> mm2;
-    std::vector<uint32_t> info2, ent;
-    size_t bytes() const { return mm2.size() * 8 + info2.size() * 4 + ent.size() * 4; }
+    std::vector<uint32_t> tab;
 };
 inline IlluminaPacked pack_illumina_tables(const IlluminaTables& T) {
     IlluminaPacked K;
     K.mm2.assign(256, 0);
     for (uint32_t q = 0; q < 256; q++) K.mm2[(q + 33u) & 255u] = T.mm_thresh[q];
-    K.info2.resize(T.info.size() * 2);
-    for (size_t i = 0; i < T.info.size(); i++) {
-        K.info2[2 * i] = (T.info[i] & 0xffffffu) * 12u;
-        K.info2[2 * i + 1] = T.info[i] >> 24;
+    const size_t n_info = T.info.size(), n_ent = T.thresh.size();
+    K.tab.resize(n_info * 2 + n_ent * 3);
+    for (size_t i = 0; i < n_info; i++) {
+        K.tab[2 * i] = (uint32_t)(n_info * 8) + (T.info[i] & 0xffffffu) * 12u;
+        K.tab[2 * i + 1] = T.info[i] >> 24;
     }
-    K.ent.resize(T.thresh.size() * 3);
-    for (size_t e = 0; e < T.thresh.size(); e++) {
-        K.ent[3 * e] = (uint32_t)T.thresh[e];
-        K.ent[3 * e + 1] = (uint32_t)(T.thresh[e] >> 32);
+    uint32_t* ent = K.tab.data() + n_info * 2;
+    for (size_t e = 0; e < n_ent; e++) {
+        ent[3 * e] = (uint32_t)T.thresh[e];
+        ent[3 * e + 1] = (uint32_t)(T.thresh[e] >> 32);
         const uint32_t c_self = ((T.quals[e] & 0xffu) + 33u) & 255u, c_alias = ((T.quals[e] >> 8) + 33u) & 255u;
-        K.ent[3 * e + 2] = (c_self * 8u) | ((c_alias * 8u) << 16);
+        ent[3 * e + 2] = (c_self * 8u) | ((c_alias * 8u) << 16);
     }
     return K;
 }

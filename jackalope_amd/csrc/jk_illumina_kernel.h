@@ -95,10 +95,10 @@ struct IlluminaKernelParams {
     uint64_t th_dup; uint32_t dup_all;
     uint64_t pool_size;
     uint32_t bc_len; uint8_t barcode[JK_MAX_BARCODE];      // encoded like the genome
-    // tables (global copies; staged to LDS when LDS_TAB), see IlluminaPacked in jk_host.h:
-    //   mm2 [256] u64 by quality character; info2 [end][pos][nt] {first entry's byte offset in ent, n entries};
-    //   ent per alias entry {thresh lo, thresh hi, 8*char kept | 8*char of the alias << 16}
-    const uint32_t* info2; const uint32_t* ent; const uint64_t* mm2;
+    // tables, see IlluminaPacked in jk_host.h: mm2 [256] u64 by quality character (always staged to LDS);
+    // tab = info2 [end][pos][nt] {byte offset of the first alias entry in tab, n entries} followed by the alias
+    // entries {thresh lo, thresh hi, 8*char kept | 8*char of the alias << 16} (staged to LDS when LDS_TAB)
+    const uint32_t* tab; const uint64_t* mm2;
     uint32_t n_info, n_entries;
     uint32_t lds_seg_off;                                  // HAP: byte offset of the per-lane segment table in LDS
 };
@@ -175,9 +175,9 @@ __device__ __forceinline__ uint32_t base_char(uint32_t code) {        // code 0.
     return __builtin_amdgcn_perm(0u, 0x47414354u, code | 0x0c0c0c00u);
 }
 
-// tables either in LDS or global (byte pointers; layouts in IlluminaKernelParams)
+// the table blob either in LDS or global (byte pointer; layout in IlluminaKernelParams)
 struct TabPtrs {
-    const uint8_t* mm; const uint8_t* info2; const uint8_t* ent;
+    const uint8_t* tab;
 };
 
 #ifdef JK_TIMELINE
@@ -234,21 +234,21 @@ __global__ void __launch_bounds__(BLOCK)
 illumina_kernel(IlluminaKernelParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     TabPtrs T;
+    // mm2 is the kernel's only static LDS object: its entries sit at compile-time LDS addresses 8*char
+    __shared__ uint64_t s_mm[256];
+    for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) s_mm[i] = P.mm2[i];
     if (LDS_TAB) {
-        // mm2 first: the kernel declares no static LDS, so its entries sit at LDS address 8*char
-        uint32_t* s_mm = reinterpret_cast<uint32_t*>(smem);
-        uint32_t* s_info = s_mm + 512;
-        uint32_t* s_ent = s_info + 2u * P.n_info;
-        const uint32_t* g_mm = reinterpret_cast<const uint32_t*>(P.mm2);
-        for (uint32_t i = threadIdx.x; i < 512u; i += blockDim.x) s_mm[i] = g_mm[i];
-        for (uint32_t i = threadIdx.x; i < 2u * P.n_info; i += blockDim.x) s_info[i] = P.info2[i];
-        for (uint32_t i = threadIdx.x; i < 3u * P.n_entries; i += blockDim.x) s_ent[i] = P.ent[i];
-        __syncthreads();
-        T.mm = smem; T.info2 = smem + 2048; T.ent = smem + 2048 + 8u * P.n_info;
+        uint32_t* s_tab = reinterpret_cast<uint32_t*>(smem);
+        const uint32_t n_words = 2u * P.n_info + 3u * P.n_entries;
+        // entry offsets become absolute LDS addresses on the way in (one add less per base)
+        const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+        for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x)
+            s_tab[i] = P.tab[i] + ((i < 2u * P.n_info && !(i & 1u)) ? lds_base : 0u);
+        T.tab = smem;
     } else {
-        T.mm = reinterpret_cast<const uint8_t*>(P.mm2); T.info2 = reinterpret_cast<const uint8_t*>(P.info2);
-        T.ent = reinterpret_cast<const uint8_t*>(P.ent);
+        T.tab = reinterpret_cast<const uint8_t*>(P.tab);
     }
+    __syncthreads();
 
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= P.n_lanes) return;
@@ -359,26 +359,41 @@ illumina_kernel(IlluminaKernelParams P) {
             uint32_t frag_pos = 0, len_now = 0, n_ins = 0, n_del = 0, ev = 0;
             const uint64_t thm = P.th_match[r], thd = P.th_del[r];
             const bool nm = P.never_match[r], nd = P.never_del[r];
-            while (len_now < L && frag_pos < fl32) {
-                JK_BAL_STEP();
-                const uint64_t x = rng();
-                if (!nm && x >= thm) {
-                    len_now++;
-                } else {
-                    const bool is_del = !nd && x >= thd;
-                    if (!is_del && len_now == L - 1) {
-                        len_now++;                       // insertion after the last base: counted, not recorded
-                    } else {
-                        const uint32_t w = frag_pos >> 6;
-                        if (w >= W) { err |= JK_KERR_TOO_MANY_DELETIONS; break; }
-                        const uint32_t vb = (is_del ? 16u : 0u) + w;
-                        uint64_t* a = evaddr(r, is_del ? 1u : 0u, w);
-                        const uint64_t old = ((ev >> vb) & 1u) ? *a : 0ULL;
-                        *a = old | (1ULL << (frag_pos & 63u));
-                        ev |= 1u << vb;
-                        if (is_del) n_del++; else { n_ins++; len_now += 2; }
-                    }
+            auto indel_event = [&](uint64_t x) {     // the draw at frag_pos was not a match
+                const bool is_del = !nd && x >= thd;
+                if (!is_del && len_now == L - 1) { len_now++; return; }       // insertion after the last base: counted, not recorded
+                const uint32_t w = frag_pos >> 6;
+                if (w >= W) { err |= JK_KERR_TOO_MANY_DELETIONS; len_now = L; return; }
+                const uint32_t vb = (is_del ? 16u : 0u) + w;
+                uint64_t* a = evaddr(r, is_del ? 1u : 0u, w);
+                const uint64_t old = ((ev >> vb) & 1u) ? *a : 0ULL;
+                *a = old | (1ULL << (frag_pos & 63u));
+                ev |= 1u << vb;
+                if (is_del) n_del++; else { n_ins++; len_now += 2; }
+            };
+            // Matches are all but ~3e-4 of the draws, and until an event the lanes of a wave are at the same
+            // position: run the draws in wave-uniform stretches (no per-lane loop condition, position counters
+            // added once per stretch), as long as every lane has steps left; an event ends the stretch.
+            for (;;) {
+                uint32_t steps = 0;       // draws this lane makes for sure if they are all matches
+                if (len_now < L && frag_pos < fl32) { const uint32_t sa = L - len_now, sb = fl32 - frag_pos; steps = sa < sb ? sa : sb; }
+                if (__builtin_amdgcn_ballot_w64(steps == 0) != 0) break;
+                uint32_t n_uni = __builtin_amdgcn_readfirstlane(steps);        // minimum over the active lanes
+                for (uint64_t less = __builtin_amdgcn_ballot_w64(steps < n_uni); less; less = __builtin_amdgcn_ballot_w64(steps < n_uni))
+                    n_uni = __builtin_amdgcn_readlane(steps, (int)__builtin_ctzll(less));
+                uint32_t k = 0; bool hit = false;
+                uint64_t x = 0;
+                while (k < n_uni) {
+                    x = rng(); k++;
+                    if (__builtin_amdgcn_ballot_w64(nm || x < thm) != 0) { hit = true; break; }
                 }
+                if (hit && (nm || x < thm)) { frag_pos += k - 1; len_now += k - 1; indel_event(x); frag_pos++; }
+                else { frag_pos += k; len_now += k; }
+            }
+            // the remaining draws of lanes that stop at different positions, one masked step at a time
+            while (len_now < L && frag_pos < fl32) {
+                const uint64_t x = rng();
+                if (!nm && x >= thm) len_now++; else indel_event(x);
                 frag_pos++;
             }
             uint64_t sp = (uint64_t)L + n_del - n_ins;
@@ -549,24 +564,31 @@ illumina_kernel(IlluminaKernelParams P) {
             // one quality + mismatch step (IlluminaQualityError::fill_read_qual, hts_illumina.h:243-256) for a TCAG
             // base with code c (c8 = 8*c) at output position `opos`: returns 8 * quality character, sets `mism`
             auto qual_step = [&](uint32_t c8, uint32_t opos, bool& mism) -> uint32_t {
-                const uint32_t* ip = reinterpret_cast<const uint32_t*>(T.info2 + (size_t)(i * L + opos) * 32u + c8);
-                const uint32_t ent_off = ip[0], nq = ip[1];
+                const uint2 inf = *reinterpret_cast<const uint2*>(T.tab + (size_t)(i * L + opos) * 32u + c8);
+                const uint32_t ent_off = inf.x, nq = inf.y;
                 const uint64_t x1 = rng();
                 // (uint64)(runif_01 * nq), src/alias_sampler.h:55: hi32(xh*nq + B) with B = hi32((xl+1)*nq) <= nq <= 255;
                 // B can only matter when the low word of xh*nq is within 256 of wrapping (2^-24 per draw)
-                const uint64_t pr = (uint64_t)(uint32_t)(x1 >> 32) * nq;
-                uint32_t idx = (uint32_t)(pr >> 32);
-                if (__builtin_amdgcn_ballot_w64((uint32_t)pr >= 0xffffff00u) != 0) {
+                const uint32_t xh = (uint32_t)(x1 >> 32);
+                uint32_t idx = __umulhi(xh, nq);
+                const uint32_t prl = xh * nq;
+                if (__builtin_amdgcn_ballot_w64(prl > 0xfffffeffu) != 0) {
                     asm volatile("" ::: "memory");
-                    if ((uint32_t)pr >= 0xffffff00u) idx = runif_index32(x1, nq);
+                    if (prl > 0xfffffeffu) idx = runif_index32(x1, nq);
                 }
-                const uint32_t* ep = reinterpret_cast<const uint32_t*>(T.ent + ent_off + idx * 12u);
-                const uint64_t th = ((uint64_t)ep[1] << 32) | ep[0];
-                const uint32_t qp = ep[2];
+                uint32_t e0, e1, qp;
+                if (LDS_TAB) {
+                    const __attribute__((address_space(3))) uint32_t* ep = (const __attribute__((address_space(3))) uint32_t*)(__umul24(idx, 12u) + ent_off);
+                    e0 = ep[0]; e1 = ep[1]; qp = ep[2];
+                } else {
+                    const uint32_t* ep = reinterpret_cast<const uint32_t*>(T.tab + (__umul24(idx, 12u) + ent_off));
+                    e0 = ep[0]; e1 = ep[1]; qp = ep[2];
+                }
+                const uint64_t th = ((uint64_t)e1 << 32) | e0;
                 const uint64_t x2 = rng();
                 const uint64_t x3 = rng();
                 const uint32_t ch8 = (x2 < th) ? (qp & 0xffffu) : (qp >> 16);
-                const uint64_t mmth = *reinterpret_cast<const uint64_t*>(T.mm + ch8);
+                const uint64_t mmth = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(s_mm) + ch8);
                 mism = x3 < mmth;
                 return ch8;
             };
@@ -736,13 +758,27 @@ __global__ void encode_bases_kernel(uint8_t* seq, uint64_t n, uint32_t* bad) {
 // each lane's 128 bytes are written by 8 consecutive threads as 16-byte pieces at the lane's final
 // offset (arbitrary alignment; unaligned dwordx4 stores are legal on gfx950 global memory).
 // ---------------------------------------------------------------------------------------------
-constexpr int CP_ROWS = 32;                     // words of every lane moved per step (128 bytes per lane; 64 and 128 measured slower)
+// Step size and LDS buffering, measured on the headline workload (one launch = 0.82 GB in, 0.82 GB out; alone, after
+// the last generator): 32 rows double-buffered 0.60 ms, 64 rows 0.44 (double) / 0.48 (single), 128 rows single 0.40,
+// 128 double / 256 single 0.36-0.38 -- but those two need 66 KB of LDS per workgroup and no longer fit next to a
+// generator workgroup (124 KB), so they only start when it has left the CU and the step ends later.
+#ifndef JK_CP_ROWS
+#define JK_CP_ROWS 128
+#endif
+#ifndef JK_CP_DB
+#define JK_CP_DB 0
+#endif
+constexpr int CP_ROWS = JK_CP_ROWS;             // words of every lane moved per step (512 bytes per lane)
+constexpr size_t CP_SLACK = (size_t)CP_ROWS * 256;   // a pool buffer is allocated this much longer: the last step of a tile loads whole rows
 __global__ void __launch_bounds__(256)
 compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
                      const uint64_t* __restrict__ lane_bytes, const uint64_t* __restrict__ out_off,
                      uint8_t* __restrict__ out, const uint64_t* __restrict__ out_base, uint32_t n_lanes) {
-    __shared__ uint32_t tile_lds[CP_ROWS * 65];
+    __shared__ uint32_t tile_lds[JK_CP_DB ? 2 : 1][CP_ROWS * 65];
     __shared__ uint32_t s_max;
+    // These waves share SIMDs with the generator of the next batch, which is older and saturates the VALU issue
+    // port: at default priority they get the left-over slots only.  They are few and memory-bound: let them issue first.
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t tile = blockIdx.x, t = threadIdx.x;
     const uint32_t lane0 = tile * 64u;
     if (t == 0) s_max = 0;
@@ -750,42 +786,60 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
     if (t < 64 && lane0 + t < n_lanes) atomicMax(&s_max, (uint32_t)lane_bytes[lane0 + t]);
     __syncthreads();
     const uint32_t max_bytes = s_max;
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(pool + pool_off[tile]);
-    const uint64_t base = out_base[0];
+    // thread -> (lane, 16-byte piece) for the write side: PIECES consecutive threads cover one lane's bytes of a step
     constexpr uint32_t PIECES = CP_ROWS / 4;                 // 16-byte pieces per lane and step
     constexpr uint32_t LANES_PER_PASS = 256 / PIECES;
-    for (uint32_t k0 = 0; k0 * 4u < max_bytes; k0 += CP_ROWS) {
-        // load CP_ROWS rows x 64 lanes coalesced
+    constexpr uint32_t PASSES = 64 / LANES_PER_PASS;
+    const uint32_t j = t % PIECES;
+    uint32_t nb[PASSES]; uint8_t* dst[PASSES];
+    const uint64_t base = out_base[0];
 #pragma unroll
-        for (uint32_t i = 0; i < (CP_ROWS * 64) / 256; i++) {
-            const uint32_t idx = t + i * 256u, row = idx >> 6, l = idx & 63u;
-            uint32_t v = 0;
-            if ((k0 + row) * 4u < max_bytes) v = src[(size_t)(k0 + row) * 64u + l];
-            tile_lds[row * 65u + l] = v;
+    for (uint32_t pass = 0; pass < PASSES; pass++) {
+        const uint32_t lane = lane0 + pass * LANES_PER_PASS + t / PIECES;
+        nb[pass] = lane < n_lanes ? (uint32_t)lane_bytes[lane] : 0u;
+        dst[pass] = out + base + (lane < n_lanes ? out_off[lane] : 0ULL) + j * 16u;
+#ifdef JK_CP_ALIGN_EXPERIMENT
+        dst[pass] = reinterpret_cast<uint8_t*>(reinterpret_cast<uintptr_t>(dst[pass]) & ~(uintptr_t)15);   // timing experiment only: wrong output
+#endif
+    }
+    // read side: a step is CP_ROWS rows of 256 bytes, contiguous in the tile: 16 bytes per thread and load, all loads of a
+    // step in flight together and the next step's loads issued before this step's stores
+    constexpr uint32_t LOADS = (CP_ROWS * 16) / 256;
+    const uint4* src = reinterpret_cast<const uint4*>(pool + pool_off[tile]);
+    uint4 r[LOADS];
+#pragma unroll
+    for (uint32_t i = 0; i < LOADS; i++) r[i] = src[t + i * 256u];
+    uint32_t buf = 0;
+    for (uint32_t k0 = 0; k0 * 4u < max_bytes; k0 += CP_ROWS, buf ^= (JK_CP_DB ? 1u : 0u)) {
+        uint32_t* L = tile_lds[buf];
+        if (!JK_CP_DB && k0) __syncthreads();
+#pragma unroll
+        for (uint32_t i = 0; i < LOADS; i++) {
+            const uint32_t idx = t + i * 256u, row = idx >> 4, l4 = (idx & 15u) * 4u;
+            uint32_t* w = L + row * 65u + l4;
+            w[0] = r[i].x; w[1] = r[i].y; w[2] = r[i].z; w[3] = r[i].w;
         }
-        __syncthreads();
-        // thread -> (lane, 16-byte piece): PIECES consecutive threads cover one lane's bytes of this step
+        __syncthreads();       // (one barrier per step: the other buffer is rewritten only after the next barrier)
+        if ((k0 + CP_ROWS) * 4u < max_bytes) {
 #pragma unroll
-        for (uint32_t pass = 0; pass < 64 / LANES_PER_PASS; pass++) {
-            const uint32_t l = pass * LANES_PER_PASS + t / PIECES, j = t % PIECES;
-            const uint32_t lane = lane0 + l;
-            if (lane < n_lanes) {
-                const uint32_t nb = (uint32_t)lane_bytes[lane];
-                const uint32_t b0 = k0 * 4u + j * 16u;          // first byte of this piece in the lane's stream
-                if (b0 < nb) {
-                    uint32_t v[4];
+            for (uint32_t i = 0; i < LOADS; i++) r[i] = src[(size_t)(k0 + CP_ROWS) * 16u + t + i * 256u];
+        }
 #pragma unroll
-                    for (uint32_t i = 0; i < 4; i++) v[i] = tile_lds[(j * 4u + i) * 65u + l];
-                    uint8_t* dst = out + base + out_off[lane] + b0;
-                    if (b0 + 16u <= nb) {
-                        __builtin_memcpy(dst, v, 16);
-                    } else {
-                        for (uint32_t b = 0; b < nb - b0; b++) dst[b] = (uint8_t)(v[b >> 2] >> ((b & 3u) * 8u));
-                    }
+        for (uint32_t pass = 0; pass < PASSES; pass++) {
+            const uint32_t l = pass * LANES_PER_PASS + t / PIECES;
+            const uint32_t b0 = k0 * 4u + j * 16u;          // first byte of this piece in the lane's stream
+            if (b0 < nb[pass]) {
+                uint32_t v[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) v[i] = L[(j * 4u + i) * 65u + l];
+                uint8_t* d = dst[pass] + (size_t)k0 * 4u;
+                if (b0 + 16u <= nb[pass]) {
+                    __builtin_memcpy(d, v, 16);
+                } else {
+                    for (uint32_t b = 0; b < nb[pass] - b0; b++) d[b] = (uint8_t)(v[b >> 2] >> ((b & 3u) * 8u));
                 }
             }
         }
-        __syncthreads();
     }
 }
 
@@ -842,6 +896,7 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t* t
 
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_block_kernel(const uint64_t* in, uint64_t* out, uint64_t* block_sums, uint32_t n) {
     __shared__ uint64_t total;
+    __builtin_amdgcn_s_setprio(3);      // see compact_pools_kernel
     const uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const uint64_t v = i < n ? in[i] : 0;
     const uint64_t ex = block_exclusive_scan(v, &total);
@@ -853,6 +908,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_block_kernel(const uint64_t* 
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_sums_kernel(uint64_t* block_sums, uint32_t nb, uint64_t* base) {
     __shared__ uint64_t total;
     __shared__ uint64_t carry;
+    __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (uint32_t base = 0; base < nb; base += SCAN_BLOCK) {
@@ -867,6 +923,7 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_sums_kernel(uint64_t* block_s
     if (threadIdx.x == 0) base[1] = base[0] + carry;
 }
 __global__ void __launch_bounds__(SCAN_BLOCK) scan_add_kernel(uint64_t* out, const uint64_t* block_sums, uint32_t n) {
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
     if (i < n) out[i] += block_sums[blockIdx.x];
 }

@@ -23,7 +23,7 @@ struct jk_session {
     uint32_t n_chroms = 0;
     // tables
     IlluminaTables tables;
-    DevBuf d_info2, d_ent, d_mm2;
+    DevBuf d_tab, d_mm2;
     bool lds_tables = false;
     size_t lds_bytes = 0, lds_launch = 0, evw_set = 0;
     uint32_t lds_seg_off = 0;
@@ -45,7 +45,8 @@ struct jk_session {
     DevBuf d_seeds, d_lane_reads, d_chrom_reads, d_pool_off;
     std::vector<Batch> batches;
     std::vector<uint64_t> batch_pool_off_index;   // index into d_pool_off of each batch's first entry
-    DevBuf d_pool[2][2] /* [ping-pong][end] */, d_out[2], d_lane_bytes[2], d_lane_off[2], d_block_sums, d_base[2], d_lane_made, d_evw, d_err;
+    int n_pool_sets = 2;              // pool sets in rotation (3 when memory allows: see plan_pools_common)
+    DevBuf d_pool[3][2] /* [set][end] */, d_out[2], d_lane_bytes[2], d_lane_off[2], d_block_sums, d_base[2], d_lane_made, d_evw, d_err;
     uint64_t out_cap = 0;
     IlluminaKernelParams kp{};                    // template, per-batch fields filled at launch
     // results of the last generate()
