@@ -176,7 +176,9 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     // generator b+1 (as its first waves retire) and ends after it; with two sets generator b+2 then waits.
     s.n_pool_sets = 2;
     for (uint32_t e = 0; e < s.n_ends; e++) s.d_pool[2][e].release();
-    if (s.batches.size() > 2) {
+    int want_sets = 3;
+    if (const char* e = std::getenv("JK_POOL_SETS")) want_sets = std::atoi(e);
+    if (s.batches.size() > 2 && want_sets >= 3) {
         size_t free_b = 0, total_b = 0;
         JK_HIP(hipMemGetInfo(&free_b, &total_b));
         if (free_b > (max_pool + 64 + CP_SLACK) * s.n_ends + total_b / 16) {
@@ -276,6 +278,7 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
             blob.insert(blob.end(), h.begin(), h.end());
         }
         hoff[g.n_chroms] = (uint32_t)blob.size();
+        blob.resize(blob.size() + 16, 0);        // the kernel reads the id prefix in 4-byte pieces, four of them unconditionally
         s.d_hdr_blob.upload(blob);
         s.d_hdr_off.upload(hoff);
     }
@@ -419,6 +422,7 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
             blob.insert(blob.end(), h.begin(), h.end());
         }
         hoff[n_cells] = (uint32_t)blob.size();
+        blob.resize(blob.size() + 16, 0);
         s.d_hdr_blob.upload(blob);
         s.d_hdr_off.upload(hoff);
     }

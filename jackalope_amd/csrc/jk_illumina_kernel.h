@@ -139,6 +139,12 @@ __device__ __forceinline__ void os_put(OutStream& s, uint32_t byte) {
     s.pos++;
     if (s.cnt >= 4u) os_store_word(s);
 }
+// 1..4 bytes at once (low byte first; the bytes of `word` above the n-th must be zero)
+__device__ __forceinline__ void os_put_n(OutStream& s, uint32_t word, uint32_t n) {
+    s.acc |= (uint64_t)word << (8u * s.cnt);
+    s.cnt += n; s.pos += n;
+    if (s.cnt >= 4u) os_store_word(s);
+}
 // write the pending bytes of the current word one by one; the stream is abandoned afterwards
 __device__ __forceinline__ void os_flush(OutStream& s) {
     for (uint32_t j = 0; j < s.cnt; j++) s.wp[j] = (uint8_t)(s.acc >> (8u * j));
@@ -146,7 +152,7 @@ __device__ __forceinline__ void os_flush(OutStream& s) {
 }
 
 struct LaneRng {
-    jk_pcg64 e;
+    jk_pcg64d e;
     __device__ __forceinline__ uint64_t operator()() { return jk_pcg_next(e); }
 };
 
@@ -289,7 +295,7 @@ illumina_kernel(IlluminaKernelParams P) {
 #define JK_BAL_STEP() do { } while (0)
 #endif
     LaneRng rng;
-    rng.e = jk_pcg_seed(P.seeds + (size_t)lane * 8);
+    rng.e = jk_pcg_limbs(jk_pcg_seed(P.seeds + (size_t)lane * 8));
     jk_gamma_state gst; gst.saved = 0.0; gst.saved_available = 0;
 
     const uint32_t L = P.read_len;
@@ -433,29 +439,70 @@ illumina_kernel(IlluminaKernelParams P) {
             // ---- FASTQ id line (fill_fq_lines, hts_illumina.cpp:286-312)
             OutStream& o = os[i];
             {
-                const uint32_t h0 = P.g.hdr_off[ci], h1 = P.g.hdr_off[ci + 1];
-                for (uint32_t h = h0; h < h1; h++) os_put(o, P.g.hdr_blob[h]);
-                uint64_t v = start, packed_lo = 0, packed_hi = 0; uint32_t nd = 0;
-                do {   // decimal digits, most significant ends up in the lowest nibble
-                    const uint64_t q = v / 10, d = v - q * 10;
-                    packed_hi = (packed_hi << 4) | (packed_lo >> 60);
-                    packed_lo = (packed_lo << 4) | d;
-                    v = q; nd++;
-                } while (v);
-                for (uint32_t d = 0; d < nd; d++) {
-                    os_put(o, '0' + (uint32_t)(packed_lo & 15u));
-                    packed_lo = (packed_lo >> 4) | (packed_hi << 60); packed_hi >>= 4;
+                // "@<genome>-<chrom>-": 4 bytes per load and append (the blob is padded, so the first four loads need no
+                // bounds; their latencies overlap)
+                const uint32_t h0 = P.g.hdr_off[ci], hlen = P.g.hdr_off[ci + 1] - h0;
+                const uint8_t* hp = P.g.hdr_blob + h0;
+                uint32_t hw[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) __builtin_memcpy(&hw[k], hp + 4u * k, 4);
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    if (4u * k < hlen) {
+                        const uint32_t n = hlen - 4u * k < 4u ? hlen - 4u * k : 4u;
+                        os_put_n(o, n < 4u ? hw[k] & ((1u << (8u * n)) - 1u) : hw[k], n);
+                    }
                 }
-                os_put(o, '-');
-                os_put(o, reverse ? 'R' : 'F');
-                if (P.paired) { os_put(o, '/'); os_put(o, '1' + i); }
-                os_put(o, '\n');
+                for (uint32_t k = 16; k < hlen; k += 4) {
+                    uint32_t w; __builtin_memcpy(&w, hp + k, 4);
+                    const uint32_t n = hlen - k < 4u ? hlen - k : 4u;
+                    os_put_n(o, n < 4u ? w & ((1u << (8u * n)) - 1u) : w, n);
+                }
+                // decimal digits of the start position: built least significant first by shifting characters into a
+                // 96-bit string, so the most significant digit ends up in the lowest byte (the first to go out)
+                uint32_t s0 = 0, s1 = 0, s2 = 0, nd = 0;
+                if (__builtin_amdgcn_ballot_w64(start >= 1000000000000ULL) != 0) {      // more than 12 digits: byte by byte
+                    uint64_t v = start, packed_lo = 0, packed_hi = 0;
+                    do {
+                        const uint64_t q = v / 10, d = v - q * 10;
+                        packed_hi = (packed_hi << 4) | (packed_lo >> 60);
+                        packed_lo = (packed_lo << 4) | d;
+                        v = q; nd++;
+                    } while (v);
+                    for (uint32_t d = 0; d < nd; d++) {
+                        os_put(o, '0' + (uint32_t)(packed_lo & 15u));
+                        packed_lo = (packed_lo >> 4) | (packed_hi << 60); packed_hi >>= 4;
+                    }
+                } else {
+                    auto push_digit = [&](uint32_t d) {
+                        s2 = (s2 << 8) | (s1 >> 24); s1 = (s1 << 8) | (s0 >> 24); s0 = (s0 << 8) | ('0' + d);
+                        nd++;
+                    };
+                    uint64_t v = start;
+                    if (__builtin_amdgcn_ballot_w64((v >> 32) != 0) != 0) {
+                        while (v >> 32) { const uint64_t q = v / 10; push_digit((uint32_t)(v - q * 10)); v = q; }
+                    }
+                    uint32_t v32 = (uint32_t)v;
+                    if (!(start >> 32) || v32) {        // (a 64-bit start whose low part came out as 0 has all its digits already)
+                        do { const uint32_t q = v32 / 10u; push_digit(v32 - q * 10u); v32 = q; } while (v32);
+                    }
+                    os_put_n(o, s0, nd < 4u ? nd : 4u);
+                    if (nd > 4u) os_put_n(o, s1, nd - 4u < 4u ? nd - 4u : 4u);
+                    if (nd > 8u) os_put_n(o, s2, nd - 8u);
+                }
+                uint32_t sfx = '-' | ((reverse ? (uint32_t)'R' : (uint32_t)'F') << 8);
+                if (P.paired) {
+                    os_put_n(o, sfx | ((uint32_t)'/' << 16) | (('1' + i) << 24), 4);
+                    os_put_n(o, '\n', 1);
+                } else {
+                    os_put_n(o, sfx | ((uint32_t)'\n' << 16), 3);
+                }
             }
             // the quality line is produced in the same pass as the bases, by its own stream that
             // starts right after the bases with "\n+\n"
             OutStream oq;
             os_begin(oq, i == 0 ? base0 : base1, o.pos + n_out);
-            os_put(oq, '\n'); os_put(oq, '+'); os_put(oq, '\n');
+            os_put_n(oq, (uint32_t)'\n' | ((uint32_t)'+' << 8) | ((uint32_t)'\n' << 16), 3);
 
             // ---- bases + qualities (fill_read / rev_comp / fill_read_qual).
             // Source position pp of the pre-indel read: pp < bc -> barcode; else forward chrom[start + pp - bc],
@@ -778,7 +825,9 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
     __shared__ uint32_t s_max;
     // These waves share SIMDs with the generator of the next batch, which is older and saturates the VALU issue
     // port: at default priority they get the left-over slots only.  They are few and memory-bound: let them issue first.
+#ifndef JK_CP_NOPRIO
     __builtin_amdgcn_s_setprio(3);
+#endif
     const uint32_t tile = blockIdx.x, t = threadIdx.x;
     const uint32_t lane0 = tile * 64u;
     if (t == 0) s_max = 0;

@@ -55,6 +55,26 @@ JK_HD uint64_t jk_pcg_next_ref(jk_pcg64& e) {
     return (x >> rot) | (x << ((64u - rot) & 63u));
 }
 
+// The state as four 32-bit limbs: a loop-carried 64-bit value has to live in an aligned register pair, and the new
+// limbs come out of different instructions, so 64-bit state costs one or two v_mov per step just to re-pair them.
+struct jk_pcg64d {
+    uint32_t s0, s1, s2, s3;
+    uint64_t inc_lo, inc_hi;
+};
+JK_HD jk_pcg64d jk_pcg_limbs(const jk_pcg64& e) {
+    jk_pcg64d d;
+    d.s0 = (uint32_t)e.s_lo; d.s1 = (uint32_t)(e.s_lo >> 32); d.s2 = (uint32_t)e.s_hi; d.s3 = (uint32_t)(e.s_hi >> 32);
+    d.inc_lo = e.inc_lo; d.inc_hi = e.inc_hi;
+    return d;
+}
+JK_HD uint64_t jk_pcg_next_ref(jk_pcg64d& d) {
+    jk_pcg64 e;
+    e.s_lo = ((uint64_t)d.s1 << 32) | d.s0; e.s_hi = ((uint64_t)d.s3 << 32) | d.s2; e.inc_lo = d.inc_lo; e.inc_hi = d.inc_hi;
+    const uint64_t r = jk_pcg_next_ref(e);
+    d.s0 = (uint32_t)e.s_lo; d.s1 = (uint32_t)(e.s_lo >> 32); d.s2 = (uint32_t)e.s_hi; d.s3 = (uint32_t)(e.s_hi >> 32);
+    return r;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(JK_PCG_PLAIN)
 // The same step written for the gfx950 VALU.  The 128x128->128 multiply-add is the hot spot of every
 // generator kernel (~1 206 steps per read pair); the compiler's expansion of the __int128 expression
@@ -66,8 +86,8 @@ JK_HD uint64_t jk_pcg_next_ref(jk_pcg64& e) {
 //     h  = s2*m0 + (c3:c2) + s1*m1 + s0*m2 + hi(t1) + cA, hi(h) += lo32(s0*m3 + s1*m2 + s2*m1 + s3*m0) + cB
 // gfx940-family hazard: a VALU result in an SGPR (carry-out / vcc) needs 2 wait states before a VALU reads
 // it, and the compiler cannot see inside asm: the block below is ordered so that this always holds.
-__device__ __forceinline__ uint64_t jk_pcg_next(jk_pcg64& e) {
-    const uint32_t s0 = (uint32_t)e.s_lo, s1 = (uint32_t)(e.s_lo >> 32), s2 = (uint32_t)e.s_hi, s3 = (uint32_t)(e.s_hi >> 32);
+__device__ __forceinline__ uint64_t jk_pcg_next(jk_pcg64d& e) {
+    const uint32_t s0 = e.s0, s1 = e.s1, s2 = e.s2, s3 = e.s3;
     const uint32_t m0 = (uint32_t)JK_PCG_MULT_LO, m1 = (uint32_t)(JK_PCG_MULT_LO >> 32);
     const uint32_t m2 = (uint32_t)JK_PCG_MULT_HI, m3 = (uint32_t)(JK_PCG_MULT_HI >> 32);
     uint64_t t0, t1, h, cA, cB, junk;
@@ -90,8 +110,7 @@ __device__ __forceinline__ uint64_t jk_pcg_next(jk_pcg64& e) {
         : [hl] "=&v"(h_lo), [hh] "=&v"(h_hi), [xl] "=&v"(x_lo), [jk] "=&s"(junk)
         : [h0] "v"((uint32_t)h), [t1h] "v"((uint32_t)(t1 >> 32)), [cA] "s"(cA), [hu] "v"(hu), [cB] "s"(cB), [n0] "v"(n0)
         : "vcc");
-    e.s_lo = ((uint64_t)n1 << 32) | n0;
-    e.s_hi = ((uint64_t)h_hi << 32) | h_lo;
+    e.s0 = n0; e.s1 = n1; e.s2 = h_lo; e.s3 = h_hi;
     // XSL-RR: rotate (hi ^ lo) right by the top 6 bits of the state; rot >= 32 swaps the two words
     // (bit-select on the sign of the high word instead of compare + vcc + two selects)
     const uint32_t x_hi = n1 ^ h_hi, rot = h_hi >> 26;
@@ -105,9 +124,17 @@ __device__ __forceinline__ uint64_t jk_pcg_next(jk_pcg64& e) {
         : [hh] "v"(h_hi), [a] "v"(a), [b] "v"(b));
     return ((uint64_t)r_hi << 32) | r_lo;
 }
+__device__ __forceinline__ uint64_t jk_pcg_next(jk_pcg64& e) {
+    jk_pcg64d d = jk_pcg_limbs(e);
+    const uint64_t r = jk_pcg_next(d);
+    e.s_lo = ((uint64_t)d.s1 << 32) | d.s0; e.s_hi = ((uint64_t)d.s3 << 32) | d.s2;
+    return r;
+}
 __host__ inline uint64_t jk_pcg_next(jk_pcg64& e) { return jk_pcg_next_ref(e); }    // host code seen by the device pass
+__host__ inline uint64_t jk_pcg_next(jk_pcg64d& e) { return jk_pcg_next_ref(e); }
 #else
 JK_HD uint64_t jk_pcg_next(jk_pcg64& e) { return jk_pcg_next_ref(e); }
+JK_HD uint64_t jk_pcg_next(jk_pcg64d& e) { return jk_pcg_next_ref(e); }
 #endif
 
 // ---------------------------------------------------------------------------------------------

@@ -172,7 +172,7 @@ pacbio_kernel(PacbioKernelParams P) {
     if (lane >= P.n_lanes) return;
 
     LaneRng rng;
-    rng.e = jk_pcg_seed(P.seeds + (size_t)lane * 8);
+    rng.e = jk_pcg_limbs(jk_pcg_seed(P.seeds + (size_t)lane * 8));
     jk_gamma_state ln_st; ln_st.saved = 0.0; ln_st.saved_available = 0;     // lognormal_distribution::_M_nd
     jk_gamma_state chi_st; chi_st.saved = 0.0; chi_st.saved_available = 0;  // chi_squared -> gamma -> _M_nd
 
