@@ -235,14 +235,25 @@ __device__ __forceinline__ int64_t hap_search(const HapDev& H, uint32_t cell, ui
 // HAP = sequence a set of haplotypes (IlluminaHaplotypes, src/hts_illumina.h:509-675, .cpp:495-558):
 // the lane walks (haplotype, chromosome) cells in order with per-cell quotas and reads bases through
 // the mutation tables instead of materialising each haplotype chromosome as the reference does.
+#ifdef JK_GEN_VGPRS
+#define JK_GEN_ATTR __attribute__((amdgpu_num_vgpr(JK_GEN_VGPRS)))
+#else
+#define JK_GEN_ATTR
+#endif
 template <bool LDS_TAB, uint32_t NE, int BLOCK, bool HAP>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) JK_GEN_ATTR
 illumina_kernel(IlluminaKernelParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
     TabPtrs T;
     // mm2 is the kernel's only static LDS object: its entries sit at compile-time LDS addresses 8*char
     __shared__ uint64_t s_mm[256];
     for (uint32_t i = threadIdx.x; i < 256u; i += blockDim.x) s_mm[i] = P.mm2[i];
+#ifndef JK_NO_PRIO_BALANCE
+    __shared__ uint32_t s_prog[16];      // [SIMD][slot]: progress of the (up to 4) waves of this workgroup on a SIMD
+    __shared__ uint32_t s_slots[4];
+    if (threadIdx.x < 16) s_prog[threadIdx.x] = 0xffffffffu;
+    if (threadIdx.x < 4) s_slots[threadIdx.x] = 0;
+#endif
     if (LDS_TAB) {
         uint32_t* s_tab = reinterpret_cast<uint32_t*>(smem);
         const uint32_t n_words = 2u * P.n_info + 3u * P.n_entries;
@@ -262,13 +273,12 @@ illumina_kernel(IlluminaKernelParams P) {
 #ifdef JK_TIMELINE
     const uint64_t tl_t0 = wall_clock64();
 #endif
-#ifdef JK_PRIO_BALANCE
-    // progress of the (up to 4) waves of this workgroup that share a SIMD, see bal_tick below
-    __shared__ uint32_t s_prog[16];
-    __shared__ uint32_t s_slots[4];
-    if (threadIdx.x < 16) s_prog[threadIdx.x] = 0xffffffffu;
-    if (threadIdx.x < 4) s_slots[threadIdx.x] = 0;
-    __syncthreads();
+#ifndef JK_NO_PRIO_BALANCE
+    // Wave balancing.  The SIMD arbiter issues oldest-first, and the lanes of a launch all have the same amount of
+    // work: left alone, the four waves of a SIMD finish at 50 %, 61 %, 76 % and 93 % of the kernel's duration
+    // (tools/timeline.py), and a wave on its own only fills ~40 % of the issue slots.  Every 64 draws a wave
+    // publishes its progress and takes the priority (s_setprio) of its rank among the waves of its SIMD, the one
+    // furthest behind highest: all waves then end within 3 % of each other and the launch is 13 % shorter.
     const uint32_t bal_simd = (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4)) & 3u;     // HW_ID[5:4]
     uint32_t bal_k = 0;
     if ((threadIdx.x & 63u) == 0) bal_k = atomicAdd(&s_slots[bal_simd], 1u);
@@ -277,7 +287,7 @@ illumina_kernel(IlluminaKernelParams P) {
     uint32_t bal_prog = 0, bal_it = 0;
     auto bal_tick = [&]() {
         if (!bal_on) return;
-        bal_prog++;
+        bal_prog += bal_it >> 6; bal_it &= 63u;
         s_prog[bal_simd * 4u + bal_k] = bal_prog;
         const uint4 pr = *reinterpret_cast<const uint4*>(&s_prog[bal_simd * 4u]);
         // waves that are ahead of this one (finished or absent ones read 0xffffffff: a constant offset)
@@ -290,9 +300,10 @@ illumina_kernel(IlluminaKernelParams P) {
         else if (rank == 2) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(3);
     };
-#define JK_BAL_STEP() do { if ((++bal_it & 15u) == 0) bal_tick(); } while (0)
+// n = draws just made (wave-uniform); the priorities are looked at again every 64 draws
+#define JK_BAL_STEP(n) do { bal_it += (n); if (bal_it >= 64u) bal_tick(); } while (0)
 #else
-#define JK_BAL_STEP() do { } while (0)
+#define JK_BAL_STEP(n) do { } while (0)
 #endif
     LaneRng rng;
     rng.e = jk_pcg_limbs(jk_pcg_seed(P.seeds + (size_t)lane * 8));
@@ -395,6 +406,7 @@ illumina_kernel(IlluminaKernelParams P) {
                 }
                 if (hit && (nm || x < thm)) { frag_pos += k - 1; len_now += k - 1; indel_event(x); frag_pos++; }
                 else { frag_pos += k; len_now += k; }
+                JK_BAL_STEP(k);
             }
             // the remaining draws of lanes that stop at different positions, one masked step at a time
             while (len_now < L && frag_pos < fl32) {
@@ -686,6 +698,7 @@ illumina_kernel(IlluminaKernelParams P) {
                         op += 4;
                     }
                     pp += 4u * nquads;
+                    JK_BAL_STEP(12u * nquads);
                     continue;
                 }
                 // ---- one base the general way
@@ -758,7 +771,7 @@ illumina_kernel(IlluminaKernelParams P) {
         }
     }
 
-#ifdef JK_PRIO_BALANCE
+#ifndef JK_NO_PRIO_BALANCE
     if (bal_on) s_prog[bal_simd * 4u + bal_k] = 0xffffffffu;
 #endif
 #pragma unroll
@@ -807,13 +820,15 @@ __global__ void encode_bases_kernel(uint8_t* seq, uint64_t n, uint32_t* bad) {
 // ---------------------------------------------------------------------------------------------
 // Step size and LDS buffering, measured on the headline workload (one launch = 0.82 GB in, 0.82 GB out; alone, after
 // the last generator): 32 rows double-buffered 0.60 ms, 64 rows 0.44 (double) / 0.48 (single), 128 rows single 0.40,
-// 128 double / 256 single 0.36-0.38 -- but those two need 66 KB of LDS per workgroup and no longer fit next to a
-// generator workgroup (124 KB), so they only start when it has left the CU and the step ends later.
+// 128 double / 256 single 0.36-0.38.  The last two need 66 KB of LDS per workgroup and do not fit next to a generator
+// workgroup (124 KB) -- which costs nothing: the generator fills the whole register file of every SIMD it runs on and,
+// with its waves balanced, leaves no tail to run in, so the compaction of a batch runs between two generator launches
+// either way (whole step 14.6 ms with 128 double, 14.9 ms with 128 single).
 #ifndef JK_CP_ROWS
 #define JK_CP_ROWS 128
 #endif
 #ifndef JK_CP_DB
-#define JK_CP_DB 0
+#define JK_CP_DB 1
 #endif
 constexpr int CP_ROWS = JK_CP_ROWS;             // words of every lane moved per step (512 bytes per lane)
 constexpr size_t CP_SLACK = (size_t)CP_ROWS * 256;   // a pool buffer is allocated this much longer: the last step of a tile loads whole rows
