@@ -171,13 +171,14 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
         s.d_base[e].alloc((s.batches.size() + 1) * 8);
     }
     s.d_lane_made.alloc(s.n_shard * 8);
-    // A third pool set takes the compaction of batch b off the critical path of generator b+2.  The generator fills
-    // the whole register file of every SIMD it runs on, so the compaction of batch b only gets going in the tail of
-    // generator b+1 (as its first waves retire) and ends after it; with two sets generator b+2 then waits.
+    // Pool sets in rotation.  The generator fills the whole register file of every SIMD it runs on, so the compaction
+    // of batch b never runs beside generator b+1 on a CU: it goes in between launches.  Measured on the headline
+    // workload: 1 set 15.1 ms per step, 2 sets 14.7, 3 sets 14.7 -- two is the default (JK_POOL_SETS=1/3 to change).
     s.n_pool_sets = 2;
     for (uint32_t e = 0; e < s.n_ends; e++) s.d_pool[2][e].release();
-    int want_sets = 3;
+    int want_sets = 2;
     if (const char* e = std::getenv("JK_POOL_SETS")) want_sets = std::atoi(e);
+    if (want_sets <= 1) s.n_pool_sets = 1;
     if (s.batches.size() > 2 && want_sets >= 3) {
         size_t free_b = 0, total_b = 0;
         JK_HIP(hipMemGetInfo(&free_b, &total_b));
