@@ -89,85 +89,75 @@ __device__ __forceinline__ uint64_t cut_point(double c, bool* all) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Ring-staged appender: bytes -> 64-bit shift register -> 32-bit words in the lane's 128-byte LDS ring
-// (layout [piece][thread][word], a lane's 16-byte pieces are contiguous for ds_read_b128) -> 16-byte
-// global stores into the lane's contiguous pool region.  Only the owning thread touches its ring.
+// Staged appender: each lane owns PB_STAGE bytes of LDS in which its text is laid down byte by byte, and whole
+// 16-byte pieces leave for the lane's contiguous pool region (the rest moves to the front).  Only the owning
+// thread touches its bytes.
 //
-// In the per-position loop the lanes of a wave fill their rings at nearly the same rate (about one byte
-// per position), so flushing is done by the whole wave at once: when ANY lane's ring is nearly full,
-// EVERY lane writes out all of its complete 16-byte pieces (rs_flush under a wave-uniform branch).  A lane
-// flushing on its own whenever its private line fills (the first version) put a ~50-instruction
-// divergent block into ~40 % of all loop iterations; synchronised, the block runs once per ~110.
+// In the per-position loop the lanes of a wave fill their stages at nearly the same rate (about one byte per
+// position), so flushing is done by the whole wave at once: when ANY lane is nearly full, EVERY lane writes out
+// all of its complete pieces (ls_flush under a wave-uniform branch): a lane flushing on its own whenever its
+// private line fills puts a ~50-instruction divergent block into ~40 % of all loop iterations.
+// Byte-granular staging is what lets the word path of pass 2 write "this position's base, then the inserted base"
+// unconditionally and merely advance the write offset by 0, 1 or 2 (a deleted or absent byte is overwritten by the
+// next one), with no shifting or masking in registers.
 // ---------------------------------------------------------------------------------------------
 constexpr int PB_BLOCK = 256;
 constexpr uint32_t PB_HIST = 16;      // depth of the per-lane history of buffer-covering reads (see pacbio_kernel)
-struct RingStream {
-    uint8_t* gp;       // global address of the first byte not yet flushed (16-byte aligned)
-    uint32_t* lds;     // this thread's slot: word w of the ring is lds[(w >> 2) * PB_BLOCK * 4 + (w & 3)]
-    uint64_t acc;      // bytes not yet in the ring, oldest in the low byte
-    uint32_t nacc;     // their number (< 4 between calls)
-    uint32_t widx;     // ring index of the next word to write (0..31)
-    uint32_t pend;     // words in the ring (0..32); the oldest one starts a 16-byte piece
+constexpr uint32_t PB_STAGE = 144;    // 128 + what one step of the word path can add beyond its flush threshold
+constexpr uint32_t PB_FLUSH_AT = 112; // wave-synchronised flush threshold of the per-position loops
+struct LinStream {
+    uint8_t* gp;       // global address of the byte staged at lds[0] (16-byte aligned)
+    uint8_t* lds;      // this lane's stage
+    uint32_t off;      // bytes staged
     uint64_t pos;      // bytes appended so far
 };
-__device__ __forceinline__ uint32_t* rs_slot(const RingStream& s, uint32_t w) { return s.lds + (w >> 2) * PB_BLOCK * 4 + (w & 3u); }
-// write out every complete 16-byte piece of this lane's ring
-__device__ __forceinline__ void rs_flush(RingStream& s) {
-    const uint32_t np = s.pend >> 2;
-    const uint32_t first = ((s.widx - s.pend) & 31u) >> 2;
+// write out every complete 16-byte piece of this lane's stage
+__device__ __forceinline__ void ls_flush(LinStream& s) {
+    const uint32_t np = s.off >> 4;
 #pragma unroll
-    for (uint32_t k = 0; k < 8; k++) {
-        if (k < np) {
-            const uint4 v = *reinterpret_cast<const uint4*>(s.lds + ((first + k) & 7u) * PB_BLOCK * 4);
-            *reinterpret_cast<uint4*>(s.gp + k * 16) = v;
-        }
+    for (uint32_t k = 0; k < PB_STAGE / 16; k++) {
+        if (k < np) *reinterpret_cast<uint4*>(s.gp + k * 16) = *reinterpret_cast<const uint4*>(s.lds + k * 16);
     }
+    if (np && (s.off & 15u)) *reinterpret_cast<uint4*>(s.lds) = *reinterpret_cast<const uint4*>(s.lds + np * 16);
     s.gp += np * 16;
-    s.pend -= np * 4;
-}
-// move one word from the shift register to the ring if there is one (the ring must have room)
-__device__ __forceinline__ void rs_drain(RingStream& s) {
-    if (s.nacc >= 4u) {
-        *rs_slot(s, s.widx) = (uint32_t)s.acc;
-        s.acc >>= 32; s.nacc -= 4u;
-        s.widx = (s.widx + 1u) & 31u; s.pend++;
-    }
-}
-// append `n` (0..4) bytes given in the low bytes of `bytes`; the caller keeps the ring from overflowing
-// (one word at most is produced per call: fewer than 4 bytes are pending on entry)
-__device__ __forceinline__ void rs_put2(RingStream& s, uint32_t bytes, uint32_t n) {
-    s.acc |= (uint64_t)bytes << (8u * s.nacc);
-    s.nacc += n; s.pos += n;
-    rs_drain(s);
+    s.off &= 15u;
 }
 // general-purpose append (headers, separators): checks for room itself
-__device__ __forceinline__ void rs_put(RingStream& s, uint32_t byte) {
-    if (s.pend >= 31u) rs_flush(s);
-    rs_put2(s, byte, 1u);
+__device__ __forceinline__ void ls_put(LinStream& s, uint32_t byte) {
+    s.lds[s.off] = (uint8_t)byte;
+    s.off++; s.pos++;
+    if (s.off >= 128u) ls_flush(s);
 }
-__device__ __forceinline__ void rs_fill(RingStream& s, uint32_t byte, uint64_t count) {
-    while (count && s.nacc) { rs_put(s, byte); count--; }
-    const uint32_t word = byte * 0x01010101u;
-    while (count >= 4) {
-        if (s.pend >= 32u) rs_flush(s);
-        *rs_slot(s, s.widx) = word;
-        s.widx = (s.widx + 1u) & 31u; s.pend++; s.pos += 4;
-        count -= 4;
+// append `n` (0..2) bytes given in the low bytes of `bytes`; the caller keeps the stage from overflowing
+__device__ __forceinline__ void ls_put2(LinStream& s, uint32_t bytes, uint32_t n) {
+    s.lds[s.off] = (uint8_t)bytes; s.lds[s.off + 1u] = (uint8_t)(bytes >> 8);
+    s.off += n; s.pos += n;
+}
+// `count` copies of one character (the quality line: half of a record): past the next 16-byte boundary they go
+// straight to the pool as 16-byte stores of a constant, without touching LDS
+__device__ __forceinline__ void ls_fill(LinStream& s, uint32_t byte, uint64_t count) {
+    while (count && (s.off & 15u)) { ls_put(s, byte); count--; }
+    if (count >= 16) {
+        ls_flush(s);                              // off is a multiple of 16: everything staged leaves, off = 0
+        const uint32_t w = byte * 0x01010101u;
+        const uint4 v = make_uint4(w, w, w, w);
+        const uint64_t n16 = count >> 4;
+        for (uint64_t k = 0; k < n16; k++) *reinterpret_cast<uint4*>(s.gp + k * 16) = v;
+        s.gp += n16 * 16; s.pos += n16 * 16;
+        count &= 15u;
     }
-    while (count) { rs_put(s, byte); count--; }
+    while (count) { ls_put(s, byte); count--; }
 }
-// end of the lane's stream: complete pieces, then the remaining words and bytes one by one
-__device__ __forceinline__ void rs_finish(RingStream& s) {
-    rs_flush(s);
-    const uint32_t first = (s.widx - s.pend) & 31u;
-    for (uint32_t k = 0; k < s.pend; k++) *reinterpret_cast<uint32_t*>(s.gp + k * 4) = *rs_slot(s, (first + k) & 31u);
-    for (uint32_t j = 0; j < s.nacc; j++) s.gp[s.pend * 4 + j] = (uint8_t)(s.acc >> (8u * j));
+// end of the lane's stream: complete pieces, then the remaining bytes one by one
+__device__ __forceinline__ void ls_finish(LinStream& s) {
+    ls_flush(s);
+    for (uint32_t j = 0; j < s.off; j++) s.gp[j] = s.lds[j];
 }
 
 template <bool HAP>
 __global__ void __launch_bounds__(PB_BLOCK, 4)       // 4 waves per SIMD -> at most 128 VGPRs
 pacbio_kernel(PacbioKernelParams P) {
-    __shared__ __align__(16) uint32_t stage[32 * PB_BLOCK];     // 128 bytes per thread
+    __shared__ __align__(16) uint8_t stage[PB_STAGE * PB_BLOCK];
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     if (lane >= P.n_lanes) return;
 
@@ -186,10 +176,10 @@ pacbio_kernel(PacbioKernelParams P) {
     const uint32_t tile = lane >> 6;
     const uint64_t tile_off = P.pool_off[tile];
     const uint64_t lane_cap = (P.pool_off[tile + 1] - tile_off) >> 6;      // a multiple of 128 (host)
-    RingStream o;
+    LinStream o;
     o.gp = P.pool + tile_off + (uint64_t)(lane & 63u) * lane_cap;           // this lane's contiguous region
-    o.lds = stage + threadIdx.x * 4;
-    o.acc = 0; o.nacc = 0; o.widx = 0; o.pend = 0; o.pos = 0;
+    o.lds = stage + threadIdx.x * PB_STAGE;
+    o.off = 0; o.pos = 0;
 
     uint32_t err = 0;
     const size_t ev_stride = (size_t)P.n_lanes;
@@ -386,7 +376,7 @@ pacbio_kernel(PacbioKernelParams P) {
             {
                 uint32_t hdr_len = P.g.hdr_off[ci + 1] - P.g.hdr_off[ci];
                 if ((uint64_t)o.pos + hdr_len + 24 + 2 * L + 8 > lane_cap) { err |= JK_KERR_POOL_OVERFLOW; break; }
-                for (uint32_t h = P.g.hdr_off[ci]; h < P.g.hdr_off[ci + 1]; h++) rs_put(o, P.g.hdr_blob[h]);
+                for (uint32_t h = P.g.hdr_off[ci]; h < P.g.hdr_off[ci + 1]; h++) ls_put(o, P.g.hdr_blob[h]);
                 uint64_t v = read_start, packed_lo = 0, packed_hi = 0; uint32_t nd = 0;
                 do {
                     const uint64_t q = v / 10, d = v - q * 10;
@@ -395,12 +385,12 @@ pacbio_kernel(PacbioKernelParams P) {
                     v = q; nd++;
                 } while (v);
                 for (uint32_t d = 0; d < nd; d++) {
-                    rs_put(o, '0' + (uint32_t)(packed_lo & 15u));
+                    ls_put(o, '0' + (uint32_t)(packed_lo & 15u));
                     packed_lo = (packed_lo >> 4) | (packed_hi << 60); packed_hi >>= 4;
                 }
-                rs_put(o, '-');
-                rs_put(o, reverse ? 'R' : 'F');
-                rs_put(o, '\n');
+                ls_put(o, '-');
+                ls_put(o, reverse ? 'R' : 'F');
+                ls_put(o, '\n');
             }
             // source walker: read[p] = forward chrom[start + p], reverse cmp(chrom[start + space - 1 - p])
             const uint8_t* const gseq = P.g.seq;
@@ -443,6 +433,11 @@ pacbio_kernel(PacbioKernelParams P) {
             };
             if (HAP) mcur = hap_search(P.h, ci, reverse ? (read_start + space - 1) : read_start);
             if (space > 0) seg_enter(0);
+            uint64_t rd_pos = 0;           // the position src_next() delivers next (the word path below does not use it)
+            // word path (reference genome): position p of the window is the byte at A + p, or the complement of the one at A - p
+            const uint64_t A = chrom_off + (reverse ? read_start + space - 1 : read_start);
+            const uint32_t rsel = reverse ? 0x04050607u : 0x03020100u;      // v_perm selectors: read order of an 8-byte chunk
+            const uint32_t rcm = reverse ? 0x02020202u : 0u;                // complement of codes 0..3
 
             // ---- pass 2: emit bases
             // Positions are handled 32 at a time (one word of event codes).  Per word the lane first finds
@@ -485,6 +480,70 @@ pacbio_kernel(PacbioKernelParams P) {
                         const bool is_nul = ((hi >> k) & 1u) ? (code >= 3u) : (code >= 4u); // index past the string: its NUL
                         nul |= is_nul ? (1u << k) : 0u;
                         res |= (uint64_t)(code & 3u) << (2u * k);
+                    }
+                }
+                // ---- word path: all 32 positions of the word from registers.  Taken when, for every lane of the wave,
+                // the positions it processes lie in its window, are TCAG, and no draw hit the NUL of the base strings.
+                // The lane loads its 32 source bytes (four unaligned 8-byte loads, put in read order and complemented by
+                // v_perm as in the Illumina kernel), maps codes to characters four at a time, patches the (rare)
+                // substitutions, and then writes per position "base, inserted base" into its stage, advancing the
+                // offset by 1 - deleted and by inserted: a byte that is not part of the read is overwritten by the next.
+                if (!HAP) {
+                    const bool word_ok = (p2 + kcut <= space) && nul == 0u;
+                    if (__builtin_amdgcn_ballot_w64(!word_ok) == 0) {
+                        uint32_t wq[8], bad = 0;
+#pragma unroll
+                        for (uint32_t g = 0; g < 4; g++) {
+                            uint32_t v[2];
+                            __builtin_memcpy(v, gseq + (reverse ? A - (p2 + 8u * g) - 7u : A + p2 + 8u * g), 8);
+                            wq[2 * g] = __builtin_amdgcn_perm(v[1], v[0], rsel) ^ rcm;
+                            wq[2 * g + 1] = __builtin_amdgcn_perm(v[1], v[0], rsel ^ 0x04040404u) ^ rcm;
+                            bad |= (v[0] | v[1]) & 0xfcfcfcfcu;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0) {
+                            if (space > buf_size) buf_size = space;
+                            const uint32_t keep = proc & ~delm, insp = insm & proc;
+                            uint32_t cw[8];
+#pragma unroll
+                            for (uint32_t q = 0; q < 8; q++) cw[q] = __builtin_amdgcn_perm(0u, 0x47414354u, wq[q]);
+                            uint32_t subm = lo & hi & proc;
+                            while (__builtin_amdgcn_ballot_w64(subm != 0u)) {
+                                if (subm) {
+                                    const uint32_t k = (uint32_t)__builtin_ctz(subm);
+                                    subm &= subm - 1u;
+                                    const uint32_t q = k >> 2, sh = 8u * (k & 3u);
+                                    uint32_t wsel = wq[0];
+#pragma unroll
+                                    for (uint32_t i = 1; i < 8; i++) wsel = (q == i) ? wq[i] : wsel;
+                                    const uint32_t nt = (wsel >> sh) & 3u;
+                                    const uint32_t code = (uint32_t)(res >> (2u * k)) & 3u;
+                                    const uint32_t sc = base_char(code + (code >= nt ? 1u : 0u)) << sh;
+                                    const uint32_t clr = ~(0xffu << sh);
+#pragma unroll
+                                    for (uint32_t i = 0; i < 8; i++) cw[i] = (q == i) ? ((cw[i] & clr) | sc) : cw[i];
+                                }
+                            }
+                            uint32_t off = o.off;
+#pragma unroll
+                            for (uint32_t q = 0; q < 8; q++) {
+                                if ((q & 1u) == 0 && __builtin_amdgcn_ballot_w64(off >= PB_FLUSH_AT)) { o.off = off; ls_flush(o); off = o.off; }
+                                // the four inserted-base codes of this quad (2 bits each), spread to bytes, as characters
+                                const uint32_t r8 = (uint32_t)(res >> (8u * q)) & 0xffu;
+                                const uint32_t ic = __builtin_amdgcn_perm(0u, 0x47414354u, (r8 | (r8 << 6) | (r8 << 12) | (r8 << 18)) & 0x03030303u);
+#pragma unroll
+                                for (uint32_t j = 0; j < 4; j++) {
+                                    const uint32_t k = 4u * q + j;
+                                    o.lds[off] = (uint8_t)(cw[q] >> (8u * j));
+                                    off += (keep >> k) & 1u;
+                                    o.lds[off] = (uint8_t)(ic >> (8u * j));
+                                    off += (insp >> k) & 1u;
+                                }
+                            }
+                            const uint32_t nb = (uint32_t)__popc(keep) + (uint32_t)__popc(insp);
+                            o.off = off; o.pos += nb; cur2 += nb;
+                            p2 += kcut;
+                            continue;
+                        }
                     }
                 }
                 // bytes of a position whose buffer character is `ch` (code `nt` if it is one of TCAG): up to two, in the
@@ -544,29 +603,31 @@ pacbio_kernel(PacbioKernelParams P) {
                 };
                 const uint32_t kmain = space > p2 ? (uint32_t)(space - p2 < kcut ? space - p2 : kcut) : 0u;
                 if (space > buf_size) buf_size = space;       // fill_read grew the string before the walk
+                if (!HAP && kmain > 0u && rd_pos != p2) seg_enter(p2);       // the word path moved on without the reader
+                rd_pos = p2 + kmain;
                 // two positions per ring check: they add at most 4 bytes to fewer than 4 pending ones, so one
                 // word at most leaves the shift register (lanes near the end of their read run fewer positions)
                 uint32_t k = 0;
                 for (; k + 2u <= kmain; k += 2u) {
-                    if (__builtin_amdgcn_ballot_w64(o.pend >= 31u)) rs_flush(o);
+                    if (__builtin_amdgcn_ballot_w64(o.off >= PB_FLUSH_AT)) ls_flush(o);
                     const uint32_t r0 = emit(k), r1 = emit(k + 1u);
                     const uint32_t n0 = r0 >> 16, n1 = r1 >> 16;
-                    rs_put2(o, (r0 & 0xffffu) | ((r1 & 0xffffu) << (8u * n0)), n0 + n1);
+                    ls_put2(o, r0 & 0xffffu, n0); ls_put2(o, r1 & 0xffffu, n1);
                     cur2 += n0 + n1;
                 }
                 for (; k < kcut; k++) {                  // at most one position of the window, then the stale ones
-                    if (__builtin_amdgcn_ballot_w64(o.pend >= 31u)) rs_flush(o);
+                    if (__builtin_amdgcn_ballot_w64(o.off >= PB_FLUSH_AT)) ls_flush(o);
                     const uint32_t r0 = k < kmain ? emit(k) : emit_stale(k);
-                    rs_put2(o, r0 & 0xffffu, r0 >> 16);
+                    ls_put2(o, r0 & 0xffffu, r0 >> 16);
                     cur2 += r0 >> 16;
                 }
                 p2 += kcut;
             }
             if (err) break;
-            rs_put(o, '\n'); rs_put(o, '+'); rs_put(o, '\n');
-            rs_fill(o, qual_left, split_pos < L ? split_pos : L);
-            rs_fill(o, qual_right, split_pos < L ? L - split_pos : 0);
-            rs_put(o, '\n');
+            ls_put(o, '\n'); ls_put(o, '+'); ls_put(o, '\n');
+            ls_fill(o, qual_left, split_pos < L ? split_pos : L);
+            ls_fill(o, qual_right, split_pos < L ? L - split_pos : 0);
+            ls_put(o, '\n');
             // this read's window now sits in the buffer: it hides every remembered read that was not longer
             while (hdepth > 0 && (hl[(2 * (hdepth - 1)) * hstride] & 0xffffffffULL) <= space) hdepth--;
             if (hdepth == PB_HIST) {                 // forget the oldest (longest) one; a position only it covered is refused
@@ -589,7 +650,7 @@ pacbio_kernel(PacbioKernelParams P) {
         if (dup && made < quota && in_pool < P.pool_size) is_dup = true;
         else { is_dup = false; if (in_pool >= P.pool_size || made >= quota) in_pool = 0; }
     }
-    rs_finish(o);
+    ls_finish(o);
     P.lane_bytes[lane] = o.pos;
     if (o.pos > lane_cap) err |= JK_KERR_POOL_OVERFLOW;
     P.lane_made[lane] = made;
