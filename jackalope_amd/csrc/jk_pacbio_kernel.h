@@ -323,29 +323,43 @@ pacbio_kernel(PacbioKernelParams P) {
             const uint32_t split32 = split_pos > 0xffffffffULL ? 0xffffffffu : (uint32_t)split_pos;
             const uint64_t spare = chrom_len - L;
             uint32_t extra = spare > 0x7fffffffULL ? 0x7fffffffu : (uint32_t)spare;
-            uint64_t word = 0;
+            // The cut points of the lane's current side live in registers and are swapped once, when `cur` reaches the
+            // split (cur never decreases); the "covers every draw" flags are almost never set, so their tests sit
+            // behind a wave-uniform switch; the two bit planes of a word are built as 32-bit values with the wave's
+            // common position as the shift, and the event counts come from popcounts per word.
+            uint64_t t_none = tL[0], t_ins = tL[1], t_del = tL[2];
+            uint32_t f = fL;
+            bool on_right = false;
+            const bool any_f = __builtin_amdgcn_ballot_w64((fL | fR) != 0u) != 0;
+            uint32_t plo = 0, phi = 0;
+            auto close_word = [&](uint32_t w) {
+                evl[(size_t)w * ev_stride] = (uint64_t)plo | ((uint64_t)phi << 32);
+                n_ins += (uint32_t)__popc(plo & ~phi); n_del += (uint32_t)__popc(phi & ~plo);
+                plo = 0; phi = 0;
+            };
             while (cur < L32) {
-                const bool right = cur >= split32;        // (the reference switches sides when cur reaches split_pos)
-                const uint64_t t_none = right ? tR[0] : tL[0], t_ins = right ? tR[1] : tL[1], t_del = right ? tR[2] : tL[2];
-                const uint32_t f = right ? fR : fL;
+                if (__builtin_amdgcn_ballot_w64(!on_right && cur >= split32)) {     // (the reference switches sides when cur reaches split_pos)
+                    if (!on_right && cur >= split32) { t_none = tR[0]; t_ins = tR[1]; t_del = tR[2]; f = fR; on_right = true; }
+                }
                 const uint64_t x = rng();
                 // same decision tree as the reference (src/hts_pacbio.h:296-314), written without divergent branches
-                const bool none = !(f & 1u) && x >= t_none;
-                const bool ins = !none && ((f & 2u) || x < t_ins);
-                const bool del = !none && !ins && ((f & 4u) || x < t_del);
+                bool none = x >= t_none, lt_ins = x < t_ins, lt_del = x < t_del;
+                if (any_f) { none = !(f & 1u) && none; lt_ins = (f & 2u) || lt_ins; lt_del = (f & 4u) || lt_del; }
+                const bool ins = !none && lt_ins;
+                const bool del = !none && !ins && lt_del;
                 const bool sub = !none && !ins && !del;
                 const bool ins_rec = ins && (cur < L32 - 1u);        // an insertion at the last base is not recorded
                 const bool del_rec = del && (extra > 0u);             // nor a deletion without spare chromosome
-                const uint32_t type = ins_rec ? 1u : (del_rec ? 2u : (sub ? 3u : 0u));
-                n_ins += ins_rec ? 1u : 0u; n_del += del_rec ? 1u : 0u;
                 extra = extra + (ins_rec ? 1u : 0u) - (del_rec ? 1u : 0u);
                 cur += (ins_rec ? 1u : 0u) + (del ? 0u : 1u);
                 if (pos >= max_pos) { err |= JK_KERR_PB_TOO_LONG; break; }
-                word |= ((uint64_t)(type & 1u) | ((uint64_t)(type >> 1) << 32)) << (pos & 31u);
+                const uint32_t bit = 1u << (pos & 31u);
+                plo |= (ins_rec || sub) ? bit : 0u;        // code bit 0: insertion (1) or substitution (3)
+                phi |= (del_rec || sub) ? bit : 0u;        // code bit 1: deletion (2) or substitution (3)
                 pos++;
-                if ((pos & 31u) == 0) { evl[(size_t)((pos >> 5) - 1u) * ev_stride] = word; word = 0; }
+                if ((pos & 31u) == 0) close_word((pos >> 5) - 1u);
             }
-            if (pos & 31u) evl[(size_t)(pos >> 5) * ev_stride] = word;
+            if (pos & 31u) close_word(pos >> 5);
         }
         if (err) break;
         uint64_t space = L + n_del - n_ins;
