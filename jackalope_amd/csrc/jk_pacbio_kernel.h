@@ -488,10 +488,10 @@ pacbio_kernel(PacbioKernelParams P) {
                         const uint32_t k = (uint32_t)__builtin_ctz(evm);
                         evm &= evm - 1u;
                         const uint64_t x = rng();
-                        uint32_t code;
-                        if ((hi >> k) & 1u) code = runif_index32(x, 3);                    // mm_nucleos[nt][(uint64)(runif_01 * 3)]
-                        else code = (uint32_t)jk_runif_index(x, 4);                        // jlp::bases[(uint64)(runif_01 * 4)]
-                        const bool is_nul = ((hi >> k) & 1u) ? (code >= 3u) : (code >= 4u); // index past the string: its NUL
+                        // substitution: mm_nucleos[nt][(uint64)(runif_01 * 3)]; insertion: jlp::bases[(uint64)(runif_01 * 4)]
+                        const uint32_t nidx = ((hi >> k) & 1u) ? 3u : 4u;
+                        const uint32_t code = runif_index32(x, nidx);
+                        const bool is_nul = code >= nidx;                                   // index past the string: its NUL
                         nul |= is_nul ? (1u << k) : 0u;
                         res |= (uint64_t)(code & 3u) << (2u * k);
                     }
