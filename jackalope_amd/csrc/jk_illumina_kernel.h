@@ -235,8 +235,10 @@ __device__ __forceinline__ int64_t hap_search(const HapDev& H, uint32_t cell, ui
 // HAP = sequence a set of haplotypes (IlluminaHaplotypes, src/hts_illumina.h:509-675, .cpp:495-558):
 // the lane walks (haplotype, chromosome) cells in order with per-cell quotas and reads bases through
 // the mutation tables instead of materialising each haplotype chromosome as the reference does.
-#ifdef JK_GEN_VGPRS
-#define JK_GEN_ATTR __attribute__((amdgpu_num_vgpr(JK_GEN_VGPRS)))
+// (experiment switch: -DJK_GEN_WAVES=5 caps the generator at 96 VGPRs, which leaves room for other kernels' waves on
+// its SIMDs -- measured in DESIGN.md section 4, not a gain)
+#ifdef JK_GEN_WAVES
+#define JK_GEN_ATTR __attribute__((amdgpu_waves_per_eu(JK_GEN_WAVES, JK_GEN_WAVES)))
 #else
 #define JK_GEN_ATTR
 #endif
@@ -659,6 +661,11 @@ illumina_kernel(IlluminaKernelParams P) {
             uint32_t grp_b = 0, grp_q = 0;          // the quad being filled by the general path
             const uint32_t rsel = reverse ? 0x04050607u : 0x03020100u;      // v_perm selectors: read order of a chunk
             const uint32_t rcm = reverse ? 0x02020202u : 0u;                // complement of codes 0..3
+            // the 8-base gear loads one block ahead: the chunk of the NEXT 8 positions is requested when this block starts,
+            // so its latency (and that of the pool stores queued before it) has a whole block to pass; it is used only if
+            // the next iteration takes the 8-base gear again (then every lane has advanced by exactly 8)
+            uint32_t pf[2] = {0, 0};
+            bool have_pf = false;
             while (op < n_out) {
                 // ---- gear choice (wave-uniform)
                 uint32_t nquads = 0;
@@ -670,12 +677,16 @@ illumina_kernel(IlluminaKernelParams P) {
                 uint32_t wlo = 0, whi = 0;
                 if (nquads == 2u) {
                     uint32_t v[2];
-                    __builtin_memcpy(v, gseq + (reverse ? A - pp - 7u : A + pp), 8);
+                    if (have_pf) { v[0] = pf[0]; v[1] = pf[1]; }
+                    else __builtin_memcpy(v, gseq + (reverse ? A - pp - 7u : A + pp), 8);
+                    __builtin_memcpy(pf, gseq + (reverse ? A - pp - 15u : A + pp + 8u), 8);      // (stays inside the buffer's padding)
+                    have_pf = true;
                     if (__builtin_amdgcn_ballot_w64(((v[0] | v[1]) & 0xfcfcfcfcu) != 0) == 0) {
                         wlo = __builtin_amdgcn_perm(v[1], v[0], rsel) ^ rcm;
                         whi = __builtin_amdgcn_perm(v[1], v[0], rsel ^ 0x04040404u) ^ rcm;
-                    } else nquads = 0;
-                } else if (nquads == 1u) {
+                    } else { nquads = 0; have_pf = false; }
+                } else have_pf = false;
+                if (nquads == 1u) {
                     uint32_t v;
                     __builtin_memcpy(&v, gseq + (reverse ? A - pp - 3u : A + pp), 4);
                     if (__builtin_amdgcn_ballot_w64((v & 0xfcfcfcfcu) != 0) == 0) wlo = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u) ^ rcm;
