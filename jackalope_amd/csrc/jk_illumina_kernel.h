@@ -603,8 +603,11 @@ illumina_kernel(IlluminaKernelParams P) {
             };
             // `nes`: the next source position that needs the general path (barcode, deletion, insertion, segment
             // change); 0 forces it for the next base (pending inserted base).
+            // (HAP: `nev` keeps the part of it that is not a segment change, for the gathering gear below)
+            uint32_t nev = 0;
             auto next_slow = [&](uint32_t pp) -> uint32_t {
                 uint32_t e = ev_any ? next_event(pp) : 0xffffffffu;
+                if (HAP) nev = e;
                 return (HAP && seg_end_pp < e) ? seg_end_pp : e;
             };
 
@@ -668,13 +671,22 @@ illumina_kernel(IlluminaKernelParams P) {
             bool have_pf = false;
             while (op < n_out) {
                 // ---- gear choice (wave-uniform)
-                uint32_t nquads = 0;
+                uint32_t nquads = 0, room = 0;
+                bool gather_gear = false;
                 if ((op & 3u) == 0) {
-                    const uint32_t room = pending ? 0u : (nes - pp < n_out - op ? nes - pp : n_out - op);    // pp <= nes unless pending
+                    room = pending ? 0u : (nes - pp < n_out - op ? nes - pp : n_out - op);    // pp <= nes unless pending
                     if (__builtin_amdgcn_ballot_w64(room < 4u) == 0)
                         nquads = __builtin_amdgcn_ballot_w64(room < 8u) == 0 ? 2u : 1u;
+                    else if (HAP) {
+                        // Haplotypes: at 1.2 mutations per kb some lane of the wave meets a segment boundary in a third of
+                        // all quads.  If segment changes are all that stands in the way, those lanes gather their four
+                        // bases one by one across the boundary and the wave still takes the 4-base gear.
+                        const uint32_t room_ev = pending ? 0u : (nev - pp < n_out - op ? nev - pp : n_out - op);
+                        if (__builtin_amdgcn_ballot_w64(room_ev < 4u) == 0) { nquads = 1u; gather_gear = true; }
+                    }
                 }
                 uint32_t wlo = 0, whi = 0;
+                bool seg_moved = false;
                 if (nquads == 2u) {
                     uint32_t v[2];
                     if (have_pf) { v[0] = pf[0]; v[1] = pf[1]; }
@@ -687,10 +699,38 @@ illumina_kernel(IlluminaKernelParams P) {
                     } else { nquads = 0; have_pf = false; }
                 } else have_pf = false;
                 if (nquads == 1u) {
-                    uint32_t v;
-                    __builtin_memcpy(&v, gseq + (reverse ? A - pp - 3u : A + pp), 4);
-                    if (__builtin_amdgcn_ballot_w64((v & 0xfcfcfcfcu) != 0) == 0) wlo = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u) ^ rcm;
-                    else nquads = 0;
+                    if (HAP && gather_gear) {
+                        const uint64_t A0 = A; const uint32_t se0 = seg_end_pp, st0 = seg_state;
+                        uint32_t w, bad;
+                        if (room >= 4u) {
+                            uint32_t v;
+                            __builtin_memcpy(&v, gseq + (reverse ? A - pp - 3u : A + pp), 4);
+                            w = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u) ^ rcm; bad = v & 0xfcfcfcfcu;
+                        } else {
+                            // one 4-byte load per segment the four positions touch: each is read as if all four lay in
+                            // that segment, and contributes the bytes of the positions that do
+                            w = 0;
+                            uint32_t filled = 0;
+                            while (filled < 4u) {
+                                while (pp + filled >= seg_end_pp) seg_enter(pp + filled);
+                                uint32_t v;
+                                __builtin_memcpy(&v, gseq + (reverse ? A - pp - 3u : A + pp), 4);
+                                const uint32_t left = seg_end_pp - (pp + filled), n = left < 4u - filled ? left : 4u - filled;
+                                const uint32_t mask = (n >= 4u ? 0xffffffffu : ((1u << (8u * n)) - 1u)) << (8u * filled);
+                                w |= (__builtin_amdgcn_perm(0u, v, rsel & 0x03030303u) ^ rcm) & mask;
+                                filled += n;
+                            }
+                            bad = w & 0xfcfcfcfcu;
+                            seg_moved = true;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) wlo = w;
+                        else { A = A0; seg_end_pp = se0; seg_state = st0; seg_moved = false; nquads = 0; }    // not TCAG somewhere: the general path redoes it
+                    } else {
+                        uint32_t v;
+                        __builtin_memcpy(&v, gseq + (reverse ? A - pp - 3u : A + pp), 4);
+                        if (__builtin_amdgcn_ballot_w64((v & 0xfcfcfcfcu) != 0) == 0) wlo = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u) ^ rcm;
+                        else nquads = 0;
+                    }
                 }
                 if (nquads) {
                     for (uint32_t qd = 0; qd < nquads; qd++) {
@@ -709,6 +749,7 @@ illumina_kernel(IlluminaKernelParams P) {
                         op += 4;
                     }
                     pp += 4u * nquads;
+                    if (HAP && seg_moved) nes = seg_end_pp < nev ? seg_end_pp : nev;     // the gathering lanes' next general position moved with their segment
                     JK_BAL_STEP(12u * nquads);
                     continue;
                 }
@@ -737,6 +778,7 @@ illumina_kernel(IlluminaKernelParams P) {
                     }
                     if (HAP) { while (pp >= seg_end_pp && pp < sp) seg_enter(pp); }
                     nes = pending ? 0u : (pp < bc ? pp : next_slow(pp));
+                    if (HAP && (pending || pp < bc)) nev = nes;
                 }
                 uint32_t q, ch;
                 if (c < 4u) {

@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--lanes", type=int, default=1 << 21)
 ap.add_argument("--haps", type=int, default=4)
+ap.add_argument("--batch-gb", type=float, default=13.5, help="pool bytes per launch and read end: 2^18 lanes of this job need 12.3 GB (default cap of the library: 8 GB)")
 a = ap.parse_args()
 
 t = time.time()
@@ -28,7 +29,7 @@ print("%d haplotypes, %d mutations: %.1f s" % (a.haps, int(hs.n_mut.sum()), time
 n_pairs = int(n_chroms * chrom_len * 30 / 300)
 words = ja.seed_words(12345, a.lanes * (16 + 16 * a.haps) + 64)
 t = time.time()
-s = ja.illumina(hs, None, 2 * n_pairs, 150, True, n_threads=a.lanes, seed_words=words, _session=True)
+s = ja.illumina(hs, None, 2 * n_pairs, 150, True, n_threads=a.lanes, seed_words=words, max_batch_bytes=int(a.batch_gb * 1e9), _session=True)
 print("open (host planning, uploads, %d lanes): %.1f s" % (a.lanes, time.time() - t), flush=True)
 with s:
     for rep in range(2):
