@@ -337,7 +337,12 @@ pacbio_kernel(PacbioKernelParams P) {
                 n_ins += (uint32_t)__popc(plo & ~phi); n_del += (uint32_t)__popc(phi & ~plo);
                 plo = 0; phi = 0;
             };
-            while (cur < L32) {
+            // (the position counter is the same in every lane that is still drawing: kept wave-uniform, the lane's own
+            // count is what it was when the lane left the loop)
+            const uint32_t Lm1 = L32 - 1u;
+            const uint32_t max_pos32 = max_pos > 0xffffffffULL ? 0xffffffffu : (uint32_t)max_pos;
+            uint32_t upos = 0;
+            while (cur < L32 && upos < max_pos32) {
                 if (__builtin_amdgcn_ballot_w64(!on_right && cur >= split32)) {     // (the reference switches sides when cur reaches split_pos)
                     if (!on_right && cur >= split32) { t_none = tR[0]; t_ins = tR[1]; t_del = tR[2]; f = fR; on_right = true; }
                 }
@@ -348,18 +353,19 @@ pacbio_kernel(PacbioKernelParams P) {
                 const bool ins = !none && lt_ins;
                 const bool del = !none && !ins && lt_del;
                 const bool sub = !none && !ins && !del;
-                const bool ins_rec = ins && (cur < L32 - 1u);        // an insertion at the last base is not recorded
+                const bool ins_rec = ins && (cur < Lm1);              // an insertion at the last base is not recorded
                 const bool del_rec = del && (extra > 0u);             // nor a deletion without spare chromosome
                 extra = extra + (ins_rec ? 1u : 0u) - (del_rec ? 1u : 0u);
                 cur += (ins_rec ? 1u : 0u) + (del ? 0u : 1u);
-                if (pos >= max_pos) { err |= JK_KERR_PB_TOO_LONG; break; }
-                const uint32_t bit = 1u << (pos & 31u);
+                const uint32_t bit = 1u << (upos & 31u);
                 plo |= (ins_rec || sub) ? bit : 0u;        // code bit 0: insertion (1) or substitution (3)
                 phi |= (del_rec || sub) ? bit : 0u;        // code bit 1: deletion (2) or substitution (3)
-                pos++;
-                if ((pos & 31u) == 0) close_word((pos >> 5) - 1u);
+                upos++;
+                if ((upos & 31u) == 0) close_word((upos >> 5) - 1u);
             }
-            if (pos & 31u) close_word(pos >> 5);
+            pos = upos;
+            if (cur < L32) err |= JK_KERR_PB_TOO_LONG;
+            else if (pos & 31u) close_word(pos >> 5);
         }
         if (err) break;
         uint64_t space = L + n_del - n_ins;
@@ -465,8 +471,8 @@ pacbio_kernel(PacbioKernelParams P) {
                 const uint32_t lo = (uint32_t)evw, hi = (uint32_t)(evw >> 32);        // bit k: code bit 0 / 1 of position k
                 const uint32_t insm = lo & ~hi, delm = hi & ~lo;
                 // smallest k in [0, 32] with cur2 + k + #ins(<k) - #del(<k) >= L (monotone in k): positions < k are processed
-                uint32_t kcut;
-                {
+                uint32_t kcut = 32u;
+                if (__builtin_amdgcn_ballot_w64(L - cur2 < 64u) != 0) {        // (far from the read's end every position of the word is processed)
                     uint32_t a = 0;                    // invariant: f(a) < L
                     const uint64_t need = L - cur2;    // > 0
 #pragma unroll
