@@ -885,7 +885,12 @@ __global__ void encode_bases_kernel(uint8_t* seq, uint64_t n, uint32_t* bad) {
 #endif
 constexpr int CP_ROWS = JK_CP_ROWS;             // words of every lane moved per step (512 bytes per lane)
 constexpr size_t CP_SLACK = (size_t)CP_ROWS * 256;   // a pool buffer is allocated this much longer: the last step of a tile loads whole rows
-__global__ void __launch_bounds__(256)
+#ifdef JK_CP_WAVES
+#define JK_CP_ATTR __attribute__((amdgpu_waves_per_eu(JK_CP_WAVES, JK_CP_WAVES)))
+#else
+#define JK_CP_ATTR
+#endif
+__global__ void __launch_bounds__(256) JK_CP_ATTR
 compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
                      const uint64_t* __restrict__ lane_bytes, const uint64_t* __restrict__ out_off,
                      uint8_t* __restrict__ out, const uint64_t* __restrict__ out_base, uint32_t n_lanes) {
