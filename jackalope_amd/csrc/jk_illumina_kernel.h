@@ -114,41 +114,32 @@ struct IlluminaKernelParams {
 // byte by byte (os_flush), so nothing is lost.
 // ---------------------------------------------------------------------------------------------
 struct OutStream {
-    uint8_t* wp;       // address of the current word (this lane's column of the tile)
-    uint64_t acc;      // pending bytes, oldest in the low byte
-    uint32_t cnt;      // number of pending bytes (0..7)
+    uint32_t acc;      // pending bytes (fewer than 4: pos & 3 of them), oldest in the low byte
     uint32_t pos;      // byte offset in the lane's stream of the next byte to append
 };
 
 constexpr uint32_t TILE_ROW = 64 * 4;      // bytes between consecutive words of one lane
 
-__device__ __forceinline__ void os_begin(OutStream& s, uint8_t* lane_base, uint32_t pos) {
-    s.wp = lane_base + (size_t)(pos >> 2) * TILE_ROW;
-    s.pos = pos; s.acc = 0; s.cnt = pos & 3u;
-}
-__device__ __forceinline__ void os_store_word(OutStream& s) {      // requires cnt >= 4
-    *reinterpret_cast<uint32_t*>(s.wp) = (uint32_t)s.acc;
-    s.acc >>= 32; s.cnt -= 4u; s.wp += TILE_ROW;
-}
-__device__ __forceinline__ void os_put_raw(OutStream& s, uint32_t byte) {   // caller stores words and tracks pos
-    s.acc |= (uint64_t)byte << (8u * s.cnt);
-    s.cnt++;
-}
-__device__ __forceinline__ void os_put(OutStream& s, uint32_t byte) {
-    os_put_raw(s, byte);
-    s.pos++;
-    if (s.cnt >= 4u) os_store_word(s);
-}
+// `col` = the lane's column in its tile: tile base (wave-uniform, so it lives in scalar registers) + 4 * (lane & 63);
+// the word that holds stream byte `pos` is at col + (pos >> 2) * TILE_ROW
+__device__ __forceinline__ uint8_t* os_word(uint8_t* col, uint32_t pos) { return col + (size_t)(pos >> 2) * TILE_ROW; }
+__device__ __forceinline__ void os_begin(OutStream& s, uint32_t pos) { s.pos = pos; s.acc = 0; }
 // 1..4 bytes at once (low byte first; the bytes of `word` above the n-th must be zero)
-__device__ __forceinline__ void os_put_n(OutStream& s, uint32_t word, uint32_t n) {
-    s.acc |= (uint64_t)word << (8u * s.cnt);
-    s.cnt += n; s.pos += n;
-    if (s.cnt >= 4u) os_store_word(s);
+__device__ __forceinline__ void os_put_n(OutStream& s, uint8_t* col, uint32_t word, uint32_t n) {
+    const uint32_t cnt = s.pos & 3u;
+    const uint64_t t = (uint64_t)word << (8u * cnt);
+    const uint32_t w = s.acc | (uint32_t)t;
+    if (cnt + n >= 4u) { *reinterpret_cast<uint32_t*>(os_word(col, s.pos)) = w; s.acc = (uint32_t)(t >> 32); }
+    else s.acc = w;
+    s.pos += n;
 }
+__device__ __forceinline__ void os_put(OutStream& s, uint8_t* col, uint32_t byte) { os_put_n(s, col, byte, 1u); }
 // write the pending bytes of the current word one by one; the stream is abandoned afterwards
-__device__ __forceinline__ void os_flush(OutStream& s) {
-    for (uint32_t j = 0; j < s.cnt; j++) s.wp[j] = (uint8_t)(s.acc >> (8u * j));
-    s.acc = 0; s.cnt = 0;
+__device__ __forceinline__ void os_flush(OutStream& s, uint8_t* col) {
+    uint8_t* wp = os_word(col, s.pos);
+    const uint32_t cnt = s.pos & 3u;
+    for (uint32_t j = 0; j < cnt; j++) wp[j] = (uint8_t)(s.acc >> (8u * j));
+    s.acc = 0;
 }
 
 struct LaneRng {
@@ -324,14 +315,14 @@ illumina_kernel(IlluminaKernelParams P) {
     uint64_t ccnt = n_cells ? P.chrom_reads[lane] : 0;
     uint32_t cur_hap = 0xffffffffu;
 
-    const uint32_t tile = lane >> 6;
+    // the tile is the wave's: its offset and capacity are wave-uniform (scalar registers), a lane only adds its column
+    const uint32_t tile = __builtin_amdgcn_readfirstlane(lane) >> 6;
     const uint64_t tile_off = P.pool_off[tile];
     const uint64_t lane_cap = (P.pool_off[tile + 1] - tile_off) >> 6;     // bytes per lane in this tile
-    uint8_t* const base0 = P.pool[0] + tile_off + (lane & 63u) * 4u;
-    uint8_t* const base1 = NE > 1 ? P.pool[1] + tile_off + (lane & 63u) * 4u : nullptr;
+    const uint32_t colb = (lane & 63u) * 4u;
     OutStream os[2];
-    os_begin(os[0], base0, 0);
-    os_begin(os[1], base1, 0);     // unused when NE == 1
+    os_begin(os[0], 0);
+    os_begin(os[1], 0);     // unused when NE == 1
 
     uint64_t frag_len = 0, frag_start = 0;
     uint32_t err = 0;
@@ -452,6 +443,7 @@ illumina_kernel(IlluminaKernelParams P) {
 
             // ---- FASTQ id line (fill_fq_lines, hts_illumina.cpp:286-312)
             OutStream& o = os[i];
+            uint8_t* const col = P.pool[i] + tile_off + colb;
             {
                 // "@<genome>-<chrom>-": 4 bytes per load and append (the blob is padded, so the first four loads need no
                 // bounds; their latencies overlap)
@@ -464,13 +456,13 @@ illumina_kernel(IlluminaKernelParams P) {
                 for (uint32_t k = 0; k < 4; k++) {
                     if (4u * k < hlen) {
                         const uint32_t n = hlen - 4u * k < 4u ? hlen - 4u * k : 4u;
-                        os_put_n(o, n < 4u ? hw[k] & ((1u << (8u * n)) - 1u) : hw[k], n);
+                        os_put_n(o, col, n < 4u ? hw[k] & ((1u << (8u * n)) - 1u) : hw[k], n);
                     }
                 }
                 for (uint32_t k = 16; k < hlen; k += 4) {
                     uint32_t w; __builtin_memcpy(&w, hp + k, 4);
                     const uint32_t n = hlen - k < 4u ? hlen - k : 4u;
-                    os_put_n(o, n < 4u ? w & ((1u << (8u * n)) - 1u) : w, n);
+                    os_put_n(o, col, n < 4u ? w & ((1u << (8u * n)) - 1u) : w, n);
                 }
                 // decimal digits of the start position: built least significant first by shifting characters into a
                 // 96-bit string, so the most significant digit ends up in the lowest byte (the first to go out)
@@ -484,7 +476,7 @@ illumina_kernel(IlluminaKernelParams P) {
                         v = q; nd++;
                     } while (v);
                     for (uint32_t d = 0; d < nd; d++) {
-                        os_put(o, '0' + (uint32_t)(packed_lo & 15u));
+                        os_put(o, col, '0' + (uint32_t)(packed_lo & 15u));
                         packed_lo = (packed_lo >> 4) | (packed_hi << 60); packed_hi >>= 4;
                     }
                 } else {
@@ -500,23 +492,23 @@ illumina_kernel(IlluminaKernelParams P) {
                     if (!(start >> 32) || v32) {        // (a 64-bit start whose low part came out as 0 has all its digits already)
                         do { const uint32_t q = v32 / 10u; push_digit(v32 - q * 10u); v32 = q; } while (v32);
                     }
-                    os_put_n(o, s0, nd < 4u ? nd : 4u);
-                    if (nd > 4u) os_put_n(o, s1, nd - 4u < 4u ? nd - 4u : 4u);
-                    if (nd > 8u) os_put_n(o, s2, nd - 8u);
+                    os_put_n(o, col, s0, nd < 4u ? nd : 4u);
+                    if (nd > 4u) os_put_n(o, col, s1, nd - 4u < 4u ? nd - 4u : 4u);
+                    if (nd > 8u) os_put_n(o, col, s2, nd - 8u);
                 }
                 uint32_t sfx = '-' | ((reverse ? (uint32_t)'R' : (uint32_t)'F') << 8);
                 if (P.paired) {
-                    os_put_n(o, sfx | ((uint32_t)'/' << 16) | (('1' + i) << 24), 4);
-                    os_put_n(o, '\n', 1);
+                    os_put_n(o, col, sfx | ((uint32_t)'/' << 16) | (('1' + i) << 24), 4);
+                    os_put_n(o, col, '\n', 1);
                 } else {
-                    os_put_n(o, sfx | ((uint32_t)'\n' << 16), 3);
+                    os_put_n(o, col, sfx | ((uint32_t)'\n' << 16), 3);
                 }
             }
             // the quality line is produced in the same pass as the bases, by its own stream that
             // starts right after the bases with "\n+\n"
             OutStream oq;
-            os_begin(oq, i == 0 ? base0 : base1, o.pos + n_out);
-            os_put_n(oq, (uint32_t)'\n' | ((uint32_t)'+' << 8) | ((uint32_t)'\n' << 16), 3);
+            os_begin(oq, o.pos + n_out);
+            os_put_n(oq, col, (uint32_t)'\n' | ((uint32_t)'+' << 8) | ((uint32_t)'\n' << 16), 3);
 
             // ---- bases + qualities (fill_read / rev_comp / fill_read_qual).
             // Source position pp of the pre-indel read: pp < bc -> barcode; else forward chrom[start + pp - bc],
@@ -617,9 +609,9 @@ illumina_kernel(IlluminaKernelParams P) {
             // Output: the lane's phase in its 4-byte words (o.cnt / oq.cnt pending bytes, < 4) does not change while
             // whole quads are appended, so a quad is merged with one 64-bit shift and leaves as one word per stream,
             // stored by every lane of the wave in the same instruction.
-            const uint32_t sh_b = 8u * o.cnt, sh_q = 8u * oq.cnt;
-            uint32_t acc_b = (uint32_t)o.acc, acc_q = (uint32_t)oq.acc;
-            uint8_t* wpb = o.wp; uint8_t* wpq = oq.wp;
+            const uint32_t sh_b = 8u * (o.pos & 3u), sh_q = 8u * (oq.pos & 3u);
+            uint32_t acc_b = o.acc, acc_q = oq.acc;
+            uint8_t* wpb = os_word(col, o.pos); uint8_t* wpq = os_word(col, oq.pos);
             auto put_quad = [&](uint32_t gb, uint32_t gq) {
                 const uint64_t tb = (uint64_t)gb << sh_b, tq = (uint64_t)gq << sh_q;
                 *reinterpret_cast<uint32_t*>(wpb) = acc_b | (uint32_t)tb; acc_b = (uint32_t)(tb >> 32); wpb += TILE_ROW;
@@ -796,13 +788,11 @@ illumina_kernel(IlluminaKernelParams P) {
                 if ((op & 3u) == 3u) { put_quad(grp_b, grp_q); grp_b = 0; grp_q = 0; }
                 op++;
             }
-            o.acc = (uint64_t)acc_b | ((uint64_t)grp_b << sh_b); o.cnt += n_out & 3u; o.wp = wpb;
-            oq.acc = (uint64_t)acc_q | ((uint64_t)grp_q << sh_q); oq.cnt += n_out & 3u; oq.wp = wpq;
-            o.pos += n_out; oq.pos += n_out;
-            if (o.cnt >= 4u) os_store_word(o);
-            if (oq.cnt >= 4u) os_store_word(oq);
-            os_put(oq, '\n');
-            os_flush(o);               // after every word store of oq above (see OutStream)
+            // the whole quads are out; the 0..3 bases of the last, partial one go through the byte appender
+            o.acc = acc_b; o.pos += n_out & ~3u; os_put_n(o, col, grp_b, n_out & 3u);
+            oq.acc = acc_q; oq.pos += n_out & ~3u; os_put_n(oq, col, grp_q, n_out & 3u);
+            os_put(oq, col, '\n');
+            os_flush(o, col);          // after every word store of oq above (see OutStream)
             o = oq;                    // the next record continues where the quality stream stopped
             reverse = !reverse;
         }
@@ -829,7 +819,7 @@ illumina_kernel(IlluminaKernelParams P) {
 #endif
 #pragma unroll
     for (uint32_t i = 0; i < NE; i++) {
-        os_flush(os[i]);
+        os_flush(os[i], P.pool[i] + tile_off + colb);
         const uint64_t nbytes = os[i].pos;
         P.lane_bytes[i][lane] = nbytes;
         if (nbytes > lane_cap) err |= JK_KERR_POOL_OVERFLOW;
