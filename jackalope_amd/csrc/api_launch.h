@@ -105,12 +105,19 @@ static void launch_generate(jk_session& s) {
         JK_HIP(hipEventRecord(s.cp_done[b], s.cp_stream));
     }
     if (!s.batches.empty()) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[s.batches.size() - 1], 0));
+    if (!s.d_result.p) s.d_result.alloc(32);
+    JK_HIP(hipMemsetAsync(s.d_result.p, 0, 32, s.stream));
+    hipLaunchKernelGGL(finish_kernel, dim3(64), dim3(256), 0, s.stream, s.d_lane_made.as<uint64_t>(), (uint64_t)s.n_shard, s.d_err.as<uint32_t>(),
+                       s.d_base[0].as<uint64_t>() + s.batches.size(),
+                       s.n_ends > 1 ? s.d_base[1].as<uint64_t>() + s.batches.size() : (const uint64_t*)nullptr, s.d_result.as<uint64_t>());
+    JK_HIP(hipGetLastError());
     JK_HIP(hipEventRecord(s.events[ev++], s.stream));
     JK_HIP(hipStreamSynchronize(s.stream));
     JK_HIP(hipStreamSynchronize(s.cp_stream));
 
-    uint32_t err = 0;
-    JK_HIP(hipMemcpy(&err, s.d_err.p, 4, hipMemcpyDeviceToHost));
+    uint64_t result[4] = {0, 0, 0, 0};
+    JK_HIP(hipMemcpy(result, s.d_result.p, sizeof(result), hipMemcpyDeviceToHost));
+    const uint32_t err = (uint32_t)result[0];
     if (err & JK_KERR_PB_ALPHA) throw Error(JK_ERR_UNSUPPORTED, "chi-square shape n/2 < 1 (chi2_params_n) is not implemented on the GPU path");
     if (err & JK_KERR_PB_MATH) throw Error(JK_ERR_UNSUPPORTED, "a PacBio parameter led to an exp/pow argument outside the range implemented on the GPU");
     if (err & JK_KERR_PB_TOO_LONG) throw Error(JK_ERR_UNSUPPORTED, "a read was longer than the GPU path's cap (9 sigma of the log-normal, or it needed > 2x its length in reference positions)");
@@ -118,14 +125,8 @@ static void launch_generate(jk_session& s) {
     if ((err & JK_KERR_POOL_OVERFLOW) && s.pacbio) throw Error(JK_ERR_RETRY, "pool overflow");
     if (err & JK_KERR_POOL_OVERFLOW) throw Error(JK_ERR_DEVICE, "internal error: a lane overflowed its pool region");
     if (err & JK_KERR_TOO_MANY_DELETIONS) throw Error(JK_ERR_UNSUPPORTED, "a read needed more than 2x read_length reference positions (deletion probability too high for the GPU path)");
-    for (uint32_t e = 0; e < s.n_ends; e++)
-        JK_HIP(hipMemcpy(&s.bytes[e], s.d_base[e].as<uint64_t>() + s.batches.size(), 8, hipMemcpyDeviceToHost));
-    {
-        std::vector<uint64_t> made(s.n_shard);
-        if (s.n_shard) JK_HIP(hipMemcpy(made.data(), s.d_lane_made.p, s.n_shard * 8, hipMemcpyDeviceToHost));
-        s.reads_made = 0;
-        for (uint64_t v : made) s.reads_made += v;
-    }
+    for (uint32_t e = 0; e < s.n_ends; e++) s.bytes[e] = result[1 + e];
+    s.reads_made = result[3];
     float t = 0;
     double gen = 0, rest = 0;
     for (size_t b = 0; b < s.batches.size(); b++) {

@@ -1040,4 +1040,25 @@ __global__ void __launch_bounds__(SCAN_BLOCK) scan_add_kernel(uint64_t* out, con
     if (i < n) out[i] += block_sums[blockIdx.x];
 }
 
+// End of a generate(): everything the host wants to know in one 32-byte record {error bits, bytes of end 0, bytes of
+// end 1, reads made}, so that the step ends with one small copy instead of three plus the whole per-lane array.
+__global__ void __launch_bounds__(256)
+finish_kernel(const uint64_t* __restrict__ lane_made, uint64_t n_lanes, const uint32_t* __restrict__ err,
+              const uint64_t* __restrict__ total0, const uint64_t* __restrict__ total1, uint64_t* __restrict__ out) {
+    __shared__ uint64_t part[4];
+    uint64_t acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_lanes; i += (uint64_t)gridDim.x * 256) acc += lane_made[i];
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0) {
+            out[0] = err[0];
+            out[1] = total0[0];
+            out[2] = total1 ? total1[0] : 0;
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(out + 3), (unsigned long long)(part[0] + part[1] + part[2] + part[3]));     // out[3] zeroed by the host
+    }
+}
+
 }  // namespace jk

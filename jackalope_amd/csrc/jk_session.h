@@ -46,7 +46,7 @@ struct jk_session {
     std::vector<Batch> batches;
     std::vector<uint64_t> batch_pool_off_index;   // index into d_pool_off of each batch's first entry
     int n_pool_sets = 2;              // pool sets in rotation (3 when memory allows: see plan_pools_common)
-    DevBuf d_pool[3][2] /* [set][end] */, d_out[2], d_lane_bytes[2], d_lane_off[2], d_block_sums, d_base[2], d_lane_made, d_evw, d_err;
+    DevBuf d_pool[3][2] /* [set][end] */, d_out[2], d_lane_bytes[2], d_lane_off[2], d_block_sums, d_base[2], d_lane_made, d_evw, d_err, d_result;
     uint64_t out_cap = 0;
     IlluminaKernelParams kp{};                    // template, per-batch fields filled at launch
     // results of the last generate()
