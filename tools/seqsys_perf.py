@@ -26,5 +26,5 @@ for k in range(0, len(args), 3):
             best = dt if best is None or dt < best else best
         sizes, reads = s.sizes(); tm = s.timing_ms()
         print("%-5s L=%3d %s: %9d reads, %.2f GB FASTQ, %.1f ms (generator kernels %.1f ms, %d launches) -> %.1f M reads/s, %.1f Gbases/s"
-              % (sys_name, L, "PE" if paired else "SE", reads, (sizes[0] + sizes[1]) / 1e9, best * 1e3, tm["generate_kernel"], s.n_batches(),
+              % (sys_name, L, "PE" if paired else "SE", reads, sum(sizes) / 1e9, best * 1e3, tm["generate_kernel"], s.n_batches(),
                  reads / best / 1e6, reads * L / best / 1e9), flush=True)
