@@ -127,9 +127,13 @@ static std::vector<uint32_t> take_lane_seeds(jk_session& s, SeedReader& seeds) {
 // quota of maximal records; a batch is a run of whole tiles.  Then all device buffers.
 // lane_cap[l] = pool bytes lane l may need.  Plans batches/tiles and allocates everything that does not
 // depend on the sequencer model.  Returns the largest number of lanes in a batch.
+// `image_hint` (PacBio): expected size of the compacted image; when the pools' total capacity (sized for the longest
+// reads) is far above it, the image buffer is allocated for the hint with headroom instead, and the compaction
+// refuses to write past it (JK_KERR_IMAGE_FULL).
 static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint64_t lanes_per_batch,
                                   const std::vector<uint64_t>& lane_cap, const std::vector<uint64_t>& lane_reads,
-                                  const std::vector<uint32_t>& lane_seeds, const std::vector<uint32_t>& quotas) {
+                                  const std::vector<uint32_t>& lane_seeds, const std::vector<uint32_t>& quotas,
+                                  uint64_t image_hint = 0) {
     s.batches.clear(); s.batch_pool_off_index.clear();
     const uint64_t max_batch = max_batch_bytes ? max_batch_bytes : (8ULL << 30);
     uint64_t max_batch_lanes = lanes_per_batch;
@@ -157,6 +161,7 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
         max_lanes = std::max(max_lanes, b.n_lanes);
         s.batches.push_back(b);
     }
+    if (image_hint) out_cap = std::min<uint64_t>(out_cap, image_hint + image_hint / 8 + (64ULL << 20));
     s.out_cap = out_cap;
     s.d_seeds.upload(lane_seeds);
     s.d_lane_reads.upload(lane_reads);

@@ -45,7 +45,8 @@ static void launch_generate(jk_session& s) {
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.cp_stream, bs, nbp, base);
             hipLaunchKernelGGL(scan_add_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lo, bs, B.n_lanes);
             hipLaunchKernelGGL(compact_linear_kernel, dim3(B.n_lanes), dim3(256), 0, s.cp_stream,
-                               s.d_pool[pp][0].as<uint8_t>(), Q.pool_off, lb, lo, s.d_out[0].as<uint8_t>(), base, B.n_lanes);
+                               s.d_pool[pp][0].as<uint8_t>(), Q.pool_off, lb, lo, s.d_out[0].as<uint8_t>(), base, B.n_lanes,
+                               s.out_cap, s.d_err.as<uint32_t>());
             JK_HIP(hipGetLastError());
             JK_HIP(hipEventRecord(s.cp_done[b], s.cp_stream));
             continue;
@@ -122,6 +123,7 @@ static void launch_generate(jk_session& s) {
     if (err & JK_KERR_PB_MATH) throw Error(JK_ERR_UNSUPPORTED, "a PacBio parameter led to an exp/pow argument outside the range implemented on the GPU");
     if (err & JK_KERR_PB_TOO_LONG) throw Error(JK_ERR_UNSUPPORTED, "a read was longer than the GPU path's cap (9 sigma of the log-normal, or it needed > 2x its length in reference positions)");
     if (err & JK_KERR_PB_SPACE) throw Error(JK_ERR_UNSUPPORTED, "a read position lies outside the reference's read buffer (undefined there: a read as long as its chromosome or a clipped duplicate with no earlier, longer read on its thread) or needs more chromosome than there is");
+    if (err & JK_KERR_IMAGE_FULL) throw Error(JK_ERR_DEVICE, "the FASTQ image of this run does not fit in device memory next to its pools: use more GPUs (lane shards) or fewer reads per call");
     if ((err & JK_KERR_POOL_OVERFLOW) && s.pacbio) throw Error(JK_ERR_RETRY, "pool overflow");
     if (err & JK_KERR_POOL_OVERFLOW) throw Error(JK_ERR_DEVICE, "internal error: a lane overflowed its pool region");
     if (err & JK_KERR_TOO_MANY_DELETIONS) throw Error(JK_ERR_UNSUPPORTED, "a read needed more than 2x read_length reference positions (deletion probability too high for the GPU path)");

@@ -13,6 +13,7 @@ struct PacbioHostModel {
     double min_exp = 0;
     uint64_t len_hi = 0;      // pool sizing: a read length few reads exceed
     uint64_t len_cap = 0;     // hard cap (event scratch)
+    double len_mean = 0;      // expected read length (sizes the FASTQ image)
 };
 
 static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a, uint64_t max_chrom) {
@@ -37,6 +38,7 @@ static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a
         const double hi = std::exp(P.ln_mu + 4.0 * a.sigma) + a.loc, cap = std::exp(P.ln_mu + 9.0 * a.sigma) + a.loc;
         M.len_hi = (uint64_t)std::max(hi, P.min_read_len + 1.0);
         M.len_cap = (uint64_t)std::max(cap, P.min_read_len + 1.0);
+        M.len_mean = std::max(std::exp(P.ln_mu + 0.5 * a.sigma * a.sigma) + a.loc, P.min_read_len);
     } else {
         if (!a.read_probs || !a.read_lens) throw Error(JK_ERR_ARG, "Probability and read lengths vector should be the same length.");
         P.use_lognormal = 0;
@@ -49,11 +51,17 @@ static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a
             M.len_hi = std::max(M.len_hi, a.read_lens[i]);
         }
         M.len_cap = M.len_hi;
+        {
+            double ps = 0, ls = 0;
+            for (uint64_t i = 0; i < a.n_read_lens; i++) { ps += a.read_probs[i]; ls += a.read_probs[i] * (double)a.read_lens[i]; }
+            M.len_mean = ps > 0 ? ls / ps : (double)M.len_hi;
+        }
         if (a.n_read_lens >= (1ULL << 31)) throw Error(JK_ERR_UNSUPPORTED, "too many custom read lengths");
         P.n_lens = (uint32_t)a.n_read_lens;
     }
     M.len_hi = std::min(M.len_hi, max_chrom);
     M.len_cap = std::min(M.len_cap, max_chrom);
+    M.len_mean = std::min(M.len_mean, (double)max_chrom);
     // passes (PacBioPassSampler): qchisq(0.9925, n(L)) for every read length that changes n
     for (int i = 0; i < 3; i++) P.cn[i] = a.chi2_params_n[i];
     for (int i = 0; i < 5; i++) P.cs[i] = a.chi2_params_s[i];
@@ -125,8 +133,12 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     std::vector<uint64_t> lane_cap(s.n_shard);
     for (uint64_t l = 0; l < s.n_shard; l++)       // per-lane regions are contiguous and hold whole 128-byte lines
         lane_cap[l] = align_up((uint64_t)((double)(lane_reads[l] * rec) * s.pool_scale) + 2 * M.len_cap + 64, 128) + 128;
+    // the image: expected bytes (mean read length) + 12.5 % + 64 MB, not the pools' worst case (every read of maximal length)
+    uint64_t n_reads_shard = 0;
+    for (uint64_t l = 0; l < s.n_shard; l++) n_reads_shard += lane_reads[l];
+    const uint64_t image_hint = n_reads_shard * (max_hdr + n_digits(max_chrom) + 3 + 2 * (uint64_t)std::ceil(M.len_mean) + 8);
     const uint32_t max_lanes = plan_pools_common(s, max_batch_bytes ? max_batch_bytes : (48ULL << 30), 1ULL << 18,
-                                                 lane_cap, lane_reads, lane_seeds, quotas);
+                                                 lane_cap, lane_reads, lane_seeds, quotas, image_hint);
     s.ev_words = (uint32_t)((2 * M.len_cap + 64 + 31) / 32);
     s.d_ev2.alloc((size_t)s.ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
     s.d_len_thresh.upload(M.len_thresh); s.d_len_alias.upload(M.len_alias); s.d_lens.upload(M.lens);

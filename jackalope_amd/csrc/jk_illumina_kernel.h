@@ -35,6 +35,7 @@ constexpr uint32_t JK_HAP_SEGS = 3;    // segments of a read window kept in the 
 
 // error bits reported through IlluminaKernelParams::err
 enum : uint32_t {
+    JK_KERR_IMAGE_FULL = 64u,          // the compacted FASTQ image would not fit the buffer allocated for it (PacBio: see plan_pools_common)
     JK_KERR_TOO_MANY_DELETIONS = 1u,   // a read end needed more source positions than the event bitmaps hold
     JK_KERR_POOL_OVERFLOW = 2u,        // internal: a lane wrote past its pool region
 };
@@ -960,14 +961,17 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
 __global__ void __launch_bounds__(256)
 compact_linear_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
                       const uint64_t* __restrict__ lane_bytes, const uint64_t* __restrict__ out_off,
-                      uint8_t* __restrict__ out, const uint64_t* __restrict__ out_base, uint32_t n_lanes) {
+                      uint8_t* __restrict__ out, const uint64_t* __restrict__ out_base, uint32_t n_lanes,
+                      uint64_t out_capacity, uint32_t* __restrict__ err) {
     const uint32_t lane = blockIdx.x;
     if (lane >= n_lanes) return;
     const uint32_t tile = lane >> 6;
     const uint64_t cap = (pool_off[tile + 1] - pool_off[tile]) >> 6;
     const uint8_t* src = pool + pool_off[tile] + (uint64_t)(lane & 63u) * cap;
-    uint8_t* dst = out + out_base[0] + out_off[lane];
     const uint64_t n = lane_bytes[lane], n16 = n >> 4;
+    // the image is allocated for the expected size, not for the pools' worst case: never write past it
+    if (out_base[0] + out_off[lane] + n > out_capacity) { if (threadIdx.x == 0) atomicOr(err, JK_KERR_IMAGE_FULL); return; }
+    uint8_t* dst = out + out_base[0] + out_off[lane];
     for (uint64_t c = threadIdx.x; c < n16; c += 256) {
         const uint4 v = *reinterpret_cast<const uint4*>(src + c * 16);
         __builtin_memcpy(dst + c * 16, &v, 16);
