@@ -635,7 +635,7 @@ illumina_kernel(IlluminaKernelParams P) {
                 }
                 uint32_t e0, e1, qp;
                 if (LDS_TAB) {
-                    const __attribute__((address_space(3))) uint32_t* ep = (const __attribute__((address_space(3))) uint32_t*)(__umul24(idx, 12u) + ent_off);
+                    const __attribute__((address_space(3))) uint32_t* ep = (const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(__umul24(idx, 12u) + ent_off);
                     e0 = ep[0]; e1 = ep[1]; qp = ep[2];
                 } else {
                     const uint32_t* ep = reinterpret_cast<const uint32_t*>(T.tab + (__umul24(idx, 12u) + ent_off));
