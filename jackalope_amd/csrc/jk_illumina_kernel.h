@@ -881,7 +881,11 @@ constexpr size_t CP_SLACK = (size_t)CP_ROWS * 256;   // a pool buffer is allocat
 #else
 #define JK_CP_ATTR
 #endif
-__global__ void __launch_bounds__(256) JK_CP_ATTR
+#ifndef JK_CP_THREADS
+#define JK_CP_THREADS 256
+#endif
+constexpr uint32_t CP_THREADS = JK_CP_THREADS;
+__global__ void __launch_bounds__(JK_CP_THREADS) JK_CP_ATTR
 compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restrict__ pool_off,
                      const uint64_t* __restrict__ lane_bytes, const uint64_t* __restrict__ out_off,
                      uint8_t* __restrict__ out, const uint64_t* __restrict__ out_base, uint32_t n_lanes) {
@@ -901,7 +905,7 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
     const uint32_t max_bytes = s_max;
     // thread -> (lane, 16-byte piece) for the write side: PIECES consecutive threads cover one lane's bytes of a step
     constexpr uint32_t PIECES = CP_ROWS / 4;                 // 16-byte pieces per lane and step
-    constexpr uint32_t LANES_PER_PASS = 256 / PIECES;
+    constexpr uint32_t LANES_PER_PASS = CP_THREADS / PIECES;
     constexpr uint32_t PASSES = 64 / LANES_PER_PASS;
     const uint32_t j = t % PIECES;
     uint32_t nb[PASSES]; uint8_t* dst[PASSES];
@@ -917,25 +921,25 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
     }
     // read side: a step is CP_ROWS rows of 256 bytes, contiguous in the tile: 16 bytes per thread and load, all loads of a
     // step in flight together and the next step's loads issued before this step's stores
-    constexpr uint32_t LOADS = (CP_ROWS * 16) / 256;
+    constexpr uint32_t LOADS = (CP_ROWS * 16) / CP_THREADS;
     const uint4* src = reinterpret_cast<const uint4*>(pool + pool_off[tile]);
     uint4 r[LOADS];
 #pragma unroll
-    for (uint32_t i = 0; i < LOADS; i++) r[i] = src[t + i * 256u];
+    for (uint32_t i = 0; i < LOADS; i++) r[i] = src[t + i * CP_THREADS];
     uint32_t buf = 0;
     for (uint32_t k0 = 0; k0 * 4u < max_bytes; k0 += CP_ROWS, buf ^= (JK_CP_DB ? 1u : 0u)) {
         uint32_t* L = tile_lds[buf];
         if (!JK_CP_DB && k0) __syncthreads();
 #pragma unroll
         for (uint32_t i = 0; i < LOADS; i++) {
-            const uint32_t idx = t + i * 256u, row = idx >> 4, l4 = (idx & 15u) * 4u;
+            const uint32_t idx = t + i * CP_THREADS, row = idx >> 4, l4 = (idx & 15u) * 4u;
             uint32_t* w = L + row * 65u + l4;
             w[0] = r[i].x; w[1] = r[i].y; w[2] = r[i].z; w[3] = r[i].w;
         }
         __syncthreads();       // (one barrier per step: the other buffer is rewritten only after the next barrier)
         if ((k0 + CP_ROWS) * 4u < max_bytes) {
 #pragma unroll
-            for (uint32_t i = 0; i < LOADS; i++) r[i] = src[(size_t)(k0 + CP_ROWS) * 16u + t + i * 256u];
+            for (uint32_t i = 0; i < LOADS; i++) r[i] = src[(size_t)(k0 + CP_ROWS) * 16u + t + i * CP_THREADS];
         }
 #pragma unroll
         for (uint32_t pass = 0; pass < PASSES; pass++) {
