@@ -260,7 +260,7 @@ def read_fasta_main(a):
     import jackalope_amd as ja
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
-    mbp = a.genome_mbp if a.genome_mbp != 100.0 else 3000.0
+    mbp = a.genome_mbp if a.genome_mbp != 100.0 else 1000.0
     n_chroms = 24
     chrom_len = int(mbp * 1e6 / n_chroms) // 80 * 80
     tmp = tempfile.mkdtemp(prefix="jk_bench_fa_")
