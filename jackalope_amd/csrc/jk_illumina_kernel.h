@@ -620,10 +620,10 @@ illumina_kernel(IlluminaKernelParams P) {
             };
             // one quality + mismatch step (IlluminaQualityError::fill_read_qual, hts_illumina.h:243-256) for a TCAG
             // base with code c (c8 = 8*c) at output position `opos`: returns 8 * quality character, sets `mism`
-            auto qual_step = [&](uint32_t c8, uint32_t opos, bool& mism) -> uint32_t {
+            // (x1 = the step's first draw: made by the caller, because a non-TCAG position uses it differently)
+            auto qual_step = [&](uint32_t c8, uint32_t opos, uint64_t x1, bool& mism) -> uint32_t {
                 const uint2 inf = *reinterpret_cast<const uint2*>(T.tab + (size_t)(i * L + opos) * 32u + c8);
                 const uint32_t ent_off = inf.x, nq = inf.y;
-                const uint64_t x1 = rng();
                 // (uint64)(runif_01 * nq), src/alias_sampler.h:55: hi32(xh*nq + B) with B = hi32((xl+1)*nq) <= nq <= 255;
                 // B can only matter when the low word of xh*nq is within 256 of wrapping (2^-24 per draw)
                 const uint32_t xh = (uint32_t)(x1 >> 32);
@@ -678,7 +678,7 @@ illumina_kernel(IlluminaKernelParams P) {
                         if (__builtin_amdgcn_ballot_w64(room_ev < 4u) == 0) { nquads = 1u; gather_gear = true; }
                     }
                 }
-                uint32_t wlo = 0, whi = 0;
+                uint32_t wlo = 0, whi = 0, nmlo = 0, nmhi = 0;
                 bool seg_moved = false;
                 if (nquads == 2u) {
                     uint32_t v[2];
@@ -686,10 +686,9 @@ illumina_kernel(IlluminaKernelParams P) {
                     else __builtin_memcpy(v, gseq + (reverse ? A - pp - 7u : A + pp), 8);
                     __builtin_memcpy(pf, gseq + (reverse ? A - pp - 15u : A + pp + 8u), 8);      // (stays inside the buffer's padding)
                     have_pf = true;
-                    if (__builtin_amdgcn_ballot_w64(((v[0] | v[1]) & 0xfcfcfcfcu) != 0) == 0) {
-                        wlo = __builtin_amdgcn_perm(v[1], v[0], rsel) ^ rcm;
-                        whi = __builtin_amdgcn_perm(v[1], v[0], rsel ^ 0x04040404u) ^ rcm;
-                    } else { nquads = 0; have_pf = false; }
+                    const uint32_t rlo = __builtin_amdgcn_perm(v[1], v[0], rsel), rhi = __builtin_amdgcn_perm(v[1], v[0], rsel ^ 0x04040404u);
+                    nmlo = rlo & 0xfcfcfcfcu; nmhi = rhi & 0xfcfcfcfcu;       // non-zero bytes: positions that are not TCAG
+                    wlo = rlo ^ rcm; whi = rhi ^ rcm;
                 } else have_pf = false;
                 if (nquads == 1u) {
                     if (HAP && gather_gear) {
@@ -721,22 +720,42 @@ illumina_kernel(IlluminaKernelParams P) {
                     } else {
                         uint32_t v;
                         __builtin_memcpy(&v, gseq + (reverse ? A - pp - 3u : A + pp), 4);
-                        if (__builtin_amdgcn_ballot_w64((v & 0xfcfcfcfcu) != 0) == 0) wlo = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u) ^ rcm;
-                        else nquads = 0;
+                        const uint32_t rlo = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u);
+                        nmlo = rlo & 0xfcfcfcfcu;
+                        wlo = rlo ^ rcm;
                     }
                 }
                 if (nquads) {
                     for (uint32_t qd = 0; qd < nquads; qd++) {
-                        const uint32_t w = qd ? whi : wlo;
+                        const uint32_t w = qd ? whi : wlo, nm = qd ? nmhi : nmlo;
                         uint32_t cw = __builtin_amdgcn_perm(0u, 0x47414354u, w);      // four codes -> "TCAG" characters
-                        const uint32_t w8 = w << 3;
+                        const uint32_t w8 = (w & 0x03030303u) << 3;     // (a non-TCAG byte must not spill into its neighbour's code)
                         uint32_t gq = 0;
+                        if (__builtin_amdgcn_ballot_w64(nm != 0u) == 0) {
 #pragma unroll
-                        for (uint32_t j = 0; j < 4; j++) {
-                            bool mism;
-                            const uint32_t ch8 = qual_step((w8 >> (8u * j)) & 0xffu, op + j, mism);
-                            gq |= j == 0 ? (ch8 >> 3) : (ch8 << (8u * j - 3u));
-                            if (mism) cw = (cw & ~(0xffu << (8u * j))) | (mismatch_char((w >> (8u * j)) & 3u) << (8u * j));
+                            for (uint32_t j = 0; j < 4; j++) {
+                                bool mism;
+                                const uint32_t ch8 = qual_step((w8 >> (8u * j)) & 0xffu, op + j, rng(), mism);
+                                gq |= j == 0 ? (ch8 >> 3) : (ch8 << (8u * j - 3u));
+                                if (mism) cw = (cw & ~(0xffu << (8u * j))) | (mismatch_char((w >> (8u * j)) & 3u) << (8u * j));
+                            }
+                        } else {
+                            // some lane has a non-TCAG base in this quad (the N runs of real assemblies put one into most
+                            // waves): every lane makes the position's first draw; such a lane turns it into the quality
+                            // of an 'N' (hts_illumina.h:237-242), the others go on with the alias step
+#pragma unroll
+                            for (uint32_t j = 0; j < 4; j++) {
+                                const uint64_t x1 = rng();
+                                if ((nm >> (8u * j)) & 0xffu) {
+                                    gq |= (uint32_t)jk_n_qual(x1) << (8u * j);
+                                    cw = (cw & ~(0xffu << (8u * j))) | ((uint32_t)'N' << (8u * j));
+                                } else {
+                                    bool mism;
+                                    const uint32_t ch8 = qual_step((w8 >> (8u * j)) & 0xffu, op + j, x1, mism);
+                                    gq |= j == 0 ? (ch8 >> 3) : (ch8 << (8u * j - 3u));
+                                    if (mism) cw = (cw & ~(0xffu << (8u * j))) | (mismatch_char((w >> (8u * j)) & 3u) << (8u * j));
+                                }
+                            }
                         }
                         put_quad(cw, gq);
                         op += 4;
@@ -776,7 +795,7 @@ illumina_kernel(IlluminaKernelParams P) {
                 uint32_t q, ch;
                 if (c < 4u) {
                     bool mism;
-                    q = qual_step(c << 3, op, mism) >> 3;
+                    q = qual_step(c << 3, op, rng(), mism) >> 3;
                     ch = base_char(c);
                     if (mism) ch = mismatch_char(c);
                 } else {
