@@ -21,7 +21,13 @@ JK_HD void eval_one(int what, const uint64_t* in, uint64_t i, uint64_t aux, uint
         case JK_OP_RUNIF_INDEX: out[i] = jk_runif_index(in[i], aux); break;
         case JK_OP_RUNIF_DOUBLE: out[i] = jk_d2u(jk_runif_double(in[i])); break;
         case JK_OP_CANONICAL: out[i] = jk_d2u(jk_canonical(in[i])); break;
-        case JK_OP_N_QUAL: out[i] = jk_n_qual(in[i]); break;
+        case JK_OP_N_QUAL:                 // on the device: the kernels' form (common path + exact routine behind a rare branch)
+#if defined(__HIP_DEVICE_COMPILE__)
+            out[i] = n_qual32(in[i]);
+#else
+            out[i] = jk_n_qual(in[i]);
+#endif
+            break;
         case JK_OP_LT_HALF: out[i] = jk_runif_lt_half(in[i]) ? 1 : 0; break;
         case JK_OP_FRAG_START: out[i] = jk_frag_start(in[i], aux); break;
         case JK_OP_LOG: out[i] = jk_d2u(jk_log(jk_u2d(in[i]))); break;

@@ -166,6 +166,20 @@ __device__ __forceinline__ uint32_t runif_index32(uint64_t x, uint32_t n) {
     return hi;
 }
 
+// jk_n_qual for the device: (x+1)*10 = b * 2^32 + lo32(a); both x87 roundings (product, then + '!') move the value by
+// less than 2^-58, so they can only matter when the fraction is within that of 1, i.e. when lo32(b) is all ones
+// (2^-32 per draw): the common path is 33 + hi32(b), the exact routine sits behind a wave-uniform branch.
+__device__ __forceinline__ uint32_t n_qual32(uint64_t x) {
+    const uint64_t a = (uint64_t)(uint32_t)x * 10u + 10u;
+    const uint64_t b = (uint64_t)(uint32_t)(x >> 32) * 10u + (a >> 32);
+    uint32_t q = 33u + (uint32_t)(b >> 32);
+    if (__builtin_amdgcn_ballot_w64((uint32_t)b == 0xffffffffu) != 0) {
+        asm volatile("" ::: "memory");
+        if ((uint32_t)b == 0xffffffffu) q = jk_n_qual(x);
+    }
+    return q;
+}
+
 // code (T0 C1 A2 G3) -> ASCII
 __device__ __forceinline__ uint32_t base_char(uint32_t code) {        // code 0..3
     // byte `code` of "TCAG" by v_perm_b32 (selector bytes 1..3 = 0x0c: constant zero): two instructions instead of
@@ -747,7 +761,7 @@ illumina_kernel(IlluminaKernelParams P) {
                             for (uint32_t j = 0; j < 4; j++) {
                                 const uint64_t x1 = rng();
                                 if ((nm >> (8u * j)) & 0xffu) {
-                                    gq |= (uint32_t)jk_n_qual(x1) << (8u * j);
+                                    gq |= n_qual32(x1) << (8u * j);
                                     cw = (cw & ~(0xffu << (8u * j))) | ((uint32_t)'N' << (8u * j));
                                 } else {
                                     bool mism;
@@ -799,7 +813,7 @@ illumina_kernel(IlluminaKernelParams P) {
                     ch = base_char(c);
                     if (mism) ch = mismatch_char(c);
                 } else {
-                    q = jk_n_qual(rng());
+                    q = n_qual32(rng());
                     ch = 'N';
                 }
                 const uint32_t bsh = 8u * (op & 3u);       // wave-uniform

@@ -38,6 +38,15 @@ def test_runif_index_32bit_kernel_form(O, built, n):
     assert (dev_eval(_abi.OP_RUNIF_INDEX32, x, n) == O.eval_many(_abi.OP_RUNIF_INDEX, x, n)).all()
 
 
+def test_n_qual_kernel_form_near_integer_boundaries(O, built):
+    """n_qual32 (what the kernels call for a non-TCAG base): inputs whose (x+1)*10 lies within a few hundred units of a
+    multiple of 2^64 -- the only place where the two x87 roundings can change the integer part."""
+    near = np.array([v for k in range(1, 11) for v in (((k << 64) + d) // 10 - 1 for d in range(-400, 401)) if 0 <= v < 2 ** 64],
+                    dtype=np.uint64)
+    x = np.concatenate([raw_inputs(200_000, seed=77), near, np.array([0, 1, 2 ** 64 - 1, 2 ** 64 - 2, 2 ** 63], dtype=np.uint64)])
+    assert (dev_eval(_abi.OP_N_QUAL, x) == O.eval_many(_abi.OP_N_QUAL, x)).all()
+
+
 @pytest.mark.parametrize("what", [_abi.OP_RUNIF_DOUBLE, _abi.OP_CANONICAL, _abi.OP_N_QUAL, _abi.OP_LT_HALF])
 def test_unary_conversions(O, built, what):
     x = raw_inputs(4_000_000, seed=200 + what)
