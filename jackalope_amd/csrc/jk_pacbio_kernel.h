@@ -520,12 +520,31 @@ pacbio_kernel(PacbioKernelParams P) {
                             wq[2 * g + 1] = __builtin_amdgcn_perm(v[1], v[0], rsel ^ 0x04040404u) ^ rcm;
                             bad |= (v[0] | v[1]) & 0xfcfcfcfcu;
                         }
-                        if (__builtin_amdgcn_ballot_w64(bad != 0u) == 0) {
+                        // Non-TCAG bytes: 'N' is copied through on both strands (cmp_map keeps it), so a word may hold them
+                        // (the N runs of real assemblies put one into most waves); any other byte goes the per-position way.
+                        auto nzb = [](uint32_t v) -> uint32_t { return (((v & 0x7f7f7f7fu) + 0x7f7f7f7fu) | v) & 0x80808080u; };   // 0x80 per non-zero byte
+                        const bool any_n = __builtin_amdgcn_ballot_w64(bad != 0u) != 0;
+                        bool chars_ok = true;
+                        if (any_n) {
+                            const uint32_t nkey = 0x4e4e4e4eu ^ rcm;        // what 'N' looks like after the strand flip of bit 1
+                            uint32_t other = 0;
+#pragma unroll
+                            for (uint32_t q = 0; q < 8; q++) other |= nzb(wq[q] & 0xfcfcfcfcu) & nzb(wq[q] ^ nkey);
+                            chars_ok = __builtin_amdgcn_ballot_w64(other != 0u) == 0;
+                        }
+                        if (chars_ok) {
                             if (space > buf_size) buf_size = space;
                             const uint32_t keep = proc & ~delm, insp = insm & proc;
                             uint32_t cw[8];
 #pragma unroll
                             for (uint32_t q = 0; q < 8; q++) cw[q] = __builtin_amdgcn_perm(0u, 0x47414354u, wq[q]);
+                            if (any_n) {
+#pragma unroll
+                                for (uint32_t q = 0; q < 8; q++) {
+                                    const uint32_t m = (nzb(wq[q] & 0xfcfcfcfcu) >> 7) * 0xffu;      // 0xff per non-TCAG byte
+                                    cw[q] = (cw[q] & ~m) | (0x4e4e4e4eu & m);
+                                }
+                            }
                             uint32_t subm = lo & hi & proc;
                             while (__builtin_amdgcn_ballot_w64(subm != 0u)) {
                                 if (subm) {
@@ -537,7 +556,8 @@ pacbio_kernel(PacbioKernelParams P) {
                                     for (uint32_t i = 1; i < 8; i++) wsel = (q == i) ? wq[i] : wsel;
                                     const uint32_t nt = (wsel >> sh) & 3u;
                                     const uint32_t code = (uint32_t)(res >> (2u * k)) & 3u;
-                                    const uint32_t sc = base_char(code + (code >= nt ? 1u : 0u)) << sh;
+                                    // (a substitution on a non-TCAG base gives 'N': mm_nucleos[4] = "NNN", src/hts.h:46)
+                                    const uint32_t sc = (((wsel >> sh) & 0xfcu) ? (uint32_t)'N' : base_char(code + (code >= nt ? 1u : 0u))) << sh;
                                     const uint32_t clr = ~(0xffu << sh);
 #pragma unroll
                                     for (uint32_t i = 0; i < 8; i++) cw[i] = (q == i) ? ((cw[i] & clr) | sc) : cw[i];
