@@ -67,6 +67,20 @@ def test_non_tcag_bases_are_copied_like_the_reference(ja, O):
     check_ref(ja, O, g, 200, 6, {"custom_read_lengths": [800, 3000]})
 
 
+def test_runs_of_n_take_the_word_path(ja, O):
+    """A genome whose only non-TCAG bytes are N -- single ones and blocks up to thousands, as in assemblies with
+    gaps: pass 2 keeps such 32-position words in registers (N copied through on both strands, a substitution on
+    an N gives N), which the scattered odd bytes of the test above never reach."""
+    rng = np.random.default_rng(46)
+    seq = np.frombuffer(b"TCAG", dtype=np.uint8)[rng.integers(0, 4, size=400_000)].copy()
+    seq[rng.integers(0, seq.size, size=seq.size // 300)] = ord("N")
+    for at, n in [(10_000, 1), (20_000, 5), (30_000, 33), (50_000, 700), (100_000, 6000), (250_000, 40_000), (399_000, 1000)]:
+        seq[at:at + n] = ord("N")
+    g = ja.RefGenome([seq])
+    check_ref(ja, O, g, 400, 70, {"custom_read_lengths": [900, 4000, 12000]})
+    check_ref(ja, O, g, 300, 5, {"custom_read_lengths": [2000, 7000], "sub_prob": 0.2, "ins_prob": 0.05, "del_prob": 0.05}, seed=2)
+
+
 def test_haplotypes(ja, O):
     ref = ja.synthetic_genome([250_000, 60_000], seed=46)
     hs = random_haplotypes(ref, 3, seed=47, sub_rate=0.01, ins_rate=0.004, del_rate=0.004)
