@@ -693,7 +693,7 @@ illumina_kernel(IlluminaKernelParams P) {
                     }
                 }
                 uint32_t wlo = 0, whi = 0, nmlo = 0, nmhi = 0;
-                bool seg_moved = false;
+                bool seg_moved = false, any_n = false;      // any_n: some lane's chunk holds a byte that is not TCAG (wave-uniform)
                 if (nquads == 2u) {
                     uint32_t v[2];
                     if (have_pf) { v[0] = pf[0]; v[1] = pf[1]; }
@@ -701,8 +701,9 @@ illumina_kernel(IlluminaKernelParams P) {
                     __builtin_memcpy(pf, gseq + (reverse ? A - pp - 15u : A + pp + 8u), 8);      // (stays inside the buffer's padding)
                     have_pf = true;
                     const uint32_t rlo = __builtin_amdgcn_perm(v[1], v[0], rsel), rhi = __builtin_amdgcn_perm(v[1], v[0], rsel ^ 0x04040404u);
-                    nmlo = rlo & 0xfcfcfcfcu; nmhi = rhi & 0xfcfcfcfcu;       // non-zero bytes: positions that are not TCAG
                     wlo = rlo ^ rcm; whi = rhi ^ rcm;
+                    any_n = __builtin_amdgcn_ballot_w64(((v[0] | v[1]) & 0xfcfcfcfcu) != 0) != 0;
+                    if (any_n) { nmlo = rlo & 0xfcfcfcfcu; nmhi = rhi & 0xfcfcfcfcu; }       // non-zero bytes: positions that are not TCAG
                 } else have_pf = false;
                 if (nquads == 1u) {
                     if (HAP && gather_gear) {
@@ -735,17 +736,18 @@ illumina_kernel(IlluminaKernelParams P) {
                         uint32_t v;
                         __builtin_memcpy(&v, gseq + (reverse ? A - pp - 3u : A + pp), 4);
                         const uint32_t rlo = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u);
-                        nmlo = rlo & 0xfcfcfcfcu;
                         wlo = rlo ^ rcm;
+                        any_n = __builtin_amdgcn_ballot_w64((v & 0xfcfcfcfcu) != 0) != 0;
+                        if (any_n) nmlo = rlo & 0xfcfcfcfcu;
                     }
                 }
                 if (nquads) {
                     for (uint32_t qd = 0; qd < nquads; qd++) {
-                        const uint32_t w = qd ? whi : wlo, nm = qd ? nmhi : nmlo;
+                        const uint32_t w = qd ? whi : wlo;
                         uint32_t cw = __builtin_amdgcn_perm(0u, 0x47414354u, w);      // four codes -> "TCAG" characters
-                        const uint32_t w8 = (w & 0x03030303u) << 3;     // (a non-TCAG byte must not spill into its neighbour's code)
                         uint32_t gq = 0;
-                        if (__builtin_amdgcn_ballot_w64(nm != 0u) == 0) {
+                        if (!any_n) {
+                            const uint32_t w8 = w << 3;
 #pragma unroll
                             for (uint32_t j = 0; j < 4; j++) {
                                 bool mism;
@@ -757,6 +759,8 @@ illumina_kernel(IlluminaKernelParams P) {
                             // some lane has a non-TCAG base in this quad (the N runs of real assemblies put one into most
                             // waves): every lane makes the position's first draw; such a lane turns it into the quality
                             // of an 'N' (hts_illumina.h:237-242), the others go on with the alias step
+                            const uint32_t nm = qd ? nmhi : nmlo;
+                            const uint32_t w8 = (w & 0x03030303u) << 3;     // (a non-TCAG byte must not spill into its neighbour's code)
 #pragma unroll
                             for (uint32_t j = 0; j < 4; j++) {
                                 const uint64_t x1 = rng();
