@@ -134,32 +134,48 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
                                   const std::vector<uint64_t>& lane_cap, const std::vector<uint64_t>& lane_reads,
                                   const std::vector<uint32_t>& lane_seeds, const std::vector<uint32_t>& quotas,
                                   uint64_t image_hint = 0) {
-    s.batches.clear(); s.batch_pool_off_index.clear();
-    const uint64_t max_batch = max_batch_bytes ? max_batch_bytes : (8ULL << 30);
     uint64_t max_batch_lanes = lanes_per_batch;
     if (const char* e = std::getenv("JK_BATCH_LANES")) { const long long v = std::atoll(e); if (v >= 64) max_batch_lanes = (uint64_t)v / 64 * 64; }
     std::vector<uint64_t> pool_off;
     uint64_t out_cap = 0, max_pool = 0;
     uint32_t max_lanes = 0;
-    uint64_t l = 0;
-    while (l < s.n_shard) {
-        Batch b{l, 0, 0};
-        s.batch_pool_off_index.push_back(pool_off.size());
-        pool_off.push_back(0);
-        uint64_t used = 0;
-        while (l < s.n_shard && b.n_lanes < max_batch_lanes) {
-            const uint64_t tl = std::min<uint64_t>(64, s.n_shard - l);
-            uint64_t mx = 0;
-            for (uint64_t k = 0; k < tl; k++) mx = std::max(mx, lane_cap[l + k]);
-            const uint64_t cap = align_up(mx, 4) * 64;
-            if (b.n_lanes > 0 && used + cap > max_batch) break;
-            used += cap; pool_off.push_back(used); b.n_lanes += (uint32_t)tl; l += tl;
+    auto plan = [&](uint64_t max_batch) {
+        s.batches.clear(); s.batch_pool_off_index.clear(); pool_off.clear();
+        out_cap = 0; max_pool = 0; max_lanes = 0;
+        uint64_t l = 0;
+        while (l < s.n_shard) {
+            Batch b{l, 0, 0};
+            s.batch_pool_off_index.push_back(pool_off.size());
+            pool_off.push_back(0);
+            uint64_t used = 0;
+            while (l < s.n_shard && b.n_lanes < max_batch_lanes) {
+                const uint64_t tl = std::min<uint64_t>(64, s.n_shard - l);
+                uint64_t mx = 0;
+                for (uint64_t k = 0; k < tl; k++) mx = std::max(mx, lane_cap[l + k]);
+                const uint64_t cap = align_up(mx, 4) * 64;
+                if (b.n_lanes > 0 && used + cap > max_batch) break;
+                used += cap; pool_off.push_back(used); b.n_lanes += (uint32_t)tl; l += tl;
+            }
+            b.pool_bytes = used;
+            out_cap += used;
+            max_pool = std::max(max_pool, used);
+            max_lanes = std::max(max_lanes, b.n_lanes);
+            s.batches.push_back(b);
         }
-        b.pool_bytes = used;
-        out_cap += used;
-        max_pool = std::max(max_pool, used);
-        max_lanes = std::max(max_lanes, b.n_lanes);
-        s.batches.push_back(b);
+    };
+    if (max_batch_bytes) plan(max_batch_bytes);
+    else {
+        // No cap given: whole launches (max_batch_lanes lanes) if two pool sets of that size fit next to the image with
+        // room to spare, else launches of at most 8 GB of pool per read end (a launch below one workgroup per CU is
+        // slower: BASELINE configs[2] at 143 pairs per lane runs 447 instead of 373 M pairs/s with whole launches)
+        plan(~0ULL);
+        if (max_pool > (8ULL << 30)) {
+            size_t free_b = 0, total_b = 0;
+            JK_HIP(hipMemGetInfo(&free_b, &total_b));
+            const uint64_t image = image_hint ? std::min<uint64_t>(out_cap, image_hint + image_hint / 8 + (64ULL << 20)) : out_cap;
+            const uint64_t need = (2 * max_pool + image) * s.n_ends + (16ULL << 30);
+            if (need > free_b) plan(8ULL << 30);
+        }
     }
     if (image_hint) out_cap = std::min<uint64_t>(out_cap, image_hint + image_hint / 8 + (64ULL << 20));
     s.out_cap = out_cap;

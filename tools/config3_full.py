@@ -14,7 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--lanes", type=int, default=1 << 21)
 ap.add_argument("--haps", type=int, default=4)
-ap.add_argument("--batch-gb", type=float, default=13.5, help="pool bytes per launch and read end: 2^18 lanes of this job need 12.3 GB (default cap of the library: 8 GB)")
+ap.add_argument("--batch-gb", type=float, default=0, help="cap on the pool bytes per launch and read end (0 = the library decides: whole 2^18-lane launches, 12.3 GB here, when they fit)")
 a = ap.parse_args()
 
 t = time.time()
