@@ -381,6 +381,23 @@ static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min
                 throw Error(JK_ERR_ARG, "mutation table points outside the reference chromosome");
         }
     }
+    {   // bucket index for hap_search (HapDev::bucket): counts of mutations below each bucket boundary, + one closing entry
+        std::vector<uint64_t> bucket_off(n_cells + 1, 0);
+        for (uint64_t k = 0; k < n_cells; k++) bucket_off[k + 1] = bucket_off[k] + (cell_size[k] >> JK_HAP_BUCKET_SHIFT) + 2;
+        std::vector<uint32_t> bucket(bucket_off[n_cells]);
+        for (uint64_t k = 0; k < n_cells; k++) {
+            const uint64_t nb = bucket_off[k + 1] - bucket_off[k];
+            uint32_t* b = bucket.data() + bucket_off[k];
+            uint64_t m = cell_off[k];
+            for (uint64_t j = 0; j < nb; j++) {
+                const uint64_t bound = j << JK_HAP_BUCKET_SHIFT;
+                while (m < cell_off[k + 1] && new_pos[m] < bound) m++;
+                b[j] = (uint32_t)(m - cell_off[k]);
+            }
+        }
+        s.d_bucket_off.upload(bucket_off);
+        s.d_bucket.upload(bucket);
+    }
     s.d_cell_off.upload(cell_off);
     s.d_new_pos.upload(new_pos);
     s.d_ref_shift.upload(ref_shift);
@@ -396,6 +413,8 @@ static void set_hap_params(const jk_session& s, HapDev& h, uint32_t n_haps) {
     h.nuc_len = s.d_nuc_len.as<uint32_t>();
     h.nuc_off = s.d_nuc_off.as<uint64_t>();
     h.cell_size = s.d_cell_size.as<uint64_t>();
+    h.bucket_off = s.d_bucket_off.as<uint64_t>();
+    h.bucket = s.d_bucket.as<uint32_t>();
     h.bc_blob = s.d_bc_blob.as<uint8_t>();
     h.bc_len = s.d_bc_len.as<uint32_t>();
     h.n_haps = n_haps;

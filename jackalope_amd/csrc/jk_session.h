@@ -38,7 +38,7 @@ struct jk_session {
     uint64_t nuc_base = 0;     // offset of the haplotypes' nucleotide blob inside d_seq
     double pool_scale = 1.25;  // PacBio: pool capacity relative to the expected bytes (grown on overflow)
     std::function<void()> replan;   // PacBio: re-plan pools after pool_scale changed
-    DevBuf d_cell_off, d_new_pos, d_ref_shift, d_nuc_len, d_nuc_off, d_cell_size, d_bc_blob, d_bc_len;
+    DevBuf d_bucket_off, d_bucket, d_cell_off, d_new_pos, d_ref_shift, d_nuc_len, d_nuc_off, d_cell_size, d_bc_blob, d_bc_len;
     // lanes of this shard
     uint64_t n_lanes_total = 0, lane_begin = 0, lane_end = 0, n_shard = 0;
     std::vector<uint64_t> pool_off_host;          // per batch-relative offsets, concatenated per batch (n+1 each)
