@@ -293,7 +293,8 @@ enum {
     JK_OP_LOG10 = 12,       /* in: bits of x            -> bits of log10(x) */
     JK_OP_QNORM = 13,       /* in: bits of p            -> bits of qnorm(p, 0, 1) (AS 241) */
     JK_OP_RUNIF_AB = 14,    /* in: (x, bits a, c.m, c.e) -> bits of (double)(a + runif_01 * c), c = b - a in x87 */
-    JK_OP_RUNIF_INDEX32 = 15 /* as RUNIF_INDEX through the kernels' 32-bit routine (jk_dev_eval; n < 2^32) */
+    JK_OP_RUNIF_INDEX32 = 15, /* as RUNIF_INDEX through the kernels' 32-bit routine (jk_dev_eval; n < 2^32) */
+    JK_OP_ALIAS_INDEX32 = 16  /* as RUNIF_INDEX through the quality step's routine (jk_dev_eval; n <= 255) */
 };
 int jk_host_eval(int what, const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out);
 int jk_dev_eval(int device, int what, const uint64_t* in, uint64_t n, uint64_t aux, uint64_t* out);

@@ -13,7 +13,7 @@ JK_OK = 0
 JK_ERR_ARG, JK_ERR_UNSUPPORTED, JK_ERR_DEVICE, JK_ERR_IO, JK_ERR_SEEDS, JK_ERR_ABORTED = 1, 2, 3, 4, 5, 6
 
 (OP_PCG_STREAM, OP_RUNIF_INDEX, OP_RUNIF_DOUBLE, OP_CANONICAL, OP_N_QUAL, OP_LT_HALF, OP_FRAG_START,
- OP_LOG, OP_SQRT, OP_GAMMA_STREAM, OP_EXP, OP_POW, OP_LOG10, OP_QNORM, OP_RUNIF_AB, OP_RUNIF_INDEX32) = range(16)
+ OP_LOG, OP_SQRT, OP_GAMMA_STREAM, OP_EXP, OP_POW, OP_LOG10, OP_QNORM, OP_RUNIF_AB, OP_RUNIF_INDEX32, OP_ALIAS_INDEX32) = range(17)
 
 
 class JackalopeHipError(RuntimeError):

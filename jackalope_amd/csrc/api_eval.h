@@ -56,6 +56,13 @@ JK_HD void eval_one(int what, const uint64_t* in, uint64_t i, uint64_t aux, uint
             out[i] = jk_runif_index(in[i], aux);
 #endif
             break;
+        case JK_OP_ALIAS_INDEX32:          // the quality step's index routine (table sizes <= 255), device only
+#if defined(__HIP_DEVICE_COMPILE__)
+            out[i] = alias_index32(in[i], (uint32_t)aux);
+#else
+            out[i] = jk_runif_index(in[i], aux);
+#endif
+            break;
         default: break;
     }
 }

@@ -171,6 +171,20 @@ __device__ __forceinline__ uint32_t runif_index32(uint64_t x, uint32_t n) {
     return hi;
 }
 
+// (uint64)(runif_01 * nq) for an alias table of nq <= 255 entries (src/alias_sampler.h:55), as the quality step uses it:
+// hi32(xh*nq + B) with B = hi32((xl+1)*nq) <= nq; B can only matter when the low word of xh*nq is within 256 of
+// wrapping (2^-24 per draw), and then the 96-bit routine decides.
+__device__ __forceinline__ uint32_t alias_index32(uint64_t x, uint32_t nq) {
+    const uint32_t xh = (uint32_t)(x >> 32);
+    uint32_t idx = __umulhi(xh, nq);
+    const uint32_t prl = xh * nq;
+    if (__builtin_amdgcn_ballot_w64(prl > 0xfffffeffu) != 0) {
+        asm volatile("" ::: "memory");
+        if (prl > 0xfffffeffu) idx = runif_index32(x, nq);
+    }
+    return idx;
+}
+
 // jk_n_qual for the device: (x+1)*10 = b * 2^32 + lo32(a); both x87 roundings (product, then + '!') move the value by
 // less than 2^-58, so they can only matter when the fraction is within that of 1, i.e. when lo32(b) is all ones
 // (2^-32 per draw): the common path is 33 + hi32(b), the exact routine sits behind a wave-uniform branch.
@@ -650,15 +664,7 @@ illumina_kernel(IlluminaKernelParams P) {
             auto qual_step = [&](uint32_t c8, uint32_t opos, uint64_t x1, bool& mism) -> uint32_t {
                 const uint2 inf = *reinterpret_cast<const uint2*>(T.tab + (size_t)(i * L + opos) * 32u + c8);
                 const uint32_t ent_off = inf.x, nq = inf.y;
-                // (uint64)(runif_01 * nq), src/alias_sampler.h:55: hi32(xh*nq + B) with B = hi32((xl+1)*nq) <= nq <= 255;
-                // B can only matter when the low word of xh*nq is within 256 of wrapping (2^-24 per draw)
-                const uint32_t xh = (uint32_t)(x1 >> 32);
-                uint32_t idx = __umulhi(xh, nq);
-                const uint32_t prl = xh * nq;
-                if (__builtin_amdgcn_ballot_w64(prl > 0xfffffeffu) != 0) {
-                    asm volatile("" ::: "memory");
-                    if (prl > 0xfffffeffu) idx = runif_index32(x1, nq);
-                }
+                const uint32_t idx = alias_index32(x1, nq);
                 uint32_t e0, e1, qp;
                 if (LDS_TAB) {
                     const __attribute__((address_space(3))) uint32_t* ep = (const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(__umul24(idx, 12u) + ent_off);

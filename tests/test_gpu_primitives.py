@@ -38,6 +38,19 @@ def test_runif_index_32bit_kernel_form(O, built, n):
     assert (dev_eval(_abi.OP_RUNIF_INDEX32, x, n) == O.eval_many(_abi.OP_RUNIF_INDEX, x, n)).all()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 37, 40, 128, 254, 255])
+def test_alias_index_of_the_quality_step(O, built, n):
+    """alias_index32: mul_hi(x_hi, n), with the 96-bit routine behind a filter on the low word of x_hi*n -- inputs whose
+    x_hi*n lands within a few hundred of a multiple of 2^32 (where the filter fires or just does not), with random low
+    words and the extreme ones."""
+    rng = np.random.default_rng(900 + n)
+    xh = np.array([v for k in range(1, n + 1) for v in (((k << 32) + d) // n for d in range(-300, 301)) if 0 <= v < 2 ** 32], dtype=np.uint64)
+    lows = np.concatenate([rng.integers(0, 2 ** 32, size=xh.size, dtype=np.uint64), np.zeros(xh.size, np.uint64),
+                           np.full(xh.size, 2 ** 32 - 1, np.uint64), np.full(xh.size, 2 ** 32 - 2, np.uint64)])
+    x = np.concatenate([(np.tile(xh, 4) << np.uint64(32)) | lows, raw_inputs(200_000, seed=500 + n)])
+    assert (dev_eval(_abi.OP_ALIAS_INDEX32, x, n) == O.eval_many(_abi.OP_RUNIF_INDEX, x, n)).all()
+
+
 def test_n_qual_kernel_form_near_integer_boundaries(O, built):
     """n_qual32 (what the kernels call for a non-TCAG base): inputs whose (x+1)*10 lies within a few hundred units of a
     multiple of 2^64 -- the only place where the two x87 roundings can change the integer part."""
