@@ -133,6 +133,18 @@ typedef struct jk_illumina_args {
     uint64_t lane_begin, lane_end;
     int32_t device;                   /* HIP device ordinal */
     uint64_t max_batch_bytes;         /* cap on device memory for one batch's read pools; 0 = default */
+    /* Set-up in O(own lanes) for multi-rank runs (seed words given as an array only).  By default a shard derives
+     * the seed-word position of its first lane by planning the haplotype-level split of every lane before it.
+     * A host that knows the position -- ranks exchange the word counts jk_session_shard_seed_words() reports, the
+     * "seed-offset reduction" of the multi-GPU design -- passes it here and only this shard's lanes are planned. */
+    int32_t seed_offset_given;
+    uint64_t seed_offset_words;       /* position (in 32-bit words, from the start of `seeds.words`) of lane_begin's first add_n_reads word */
+    /* One-shot entry points only (jk_illumina_ref / jk_illumina_hap): generate on several devices of this node, one
+     * host thread per device, device k taking the k-th contiguous block of lanes; the files are the same as with one
+     * device.  n_devices = 0: `device` alone.  (The reference's analogue: OpenMP threads over one shared sink,
+     * src/hts.h:357-417.) */
+    const int32_t* devices;
+    uint32_t n_devices;
 } jk_illumina_args;
 
 /* Arguments of pacbio_ref_cpp / pacbio_hap_cpp, same names and meaning (src/hts_pacbio.cpp:579-602, :646-671). */
@@ -163,6 +175,10 @@ typedef struct jk_pacbio_args {
     uint64_t lane_begin, lane_end;
     int32_t device;
     uint64_t max_batch_bytes;
+    int32_t seed_offset_given;        /* as in jk_illumina_args */
+    uint64_t seed_offset_words;
+    const int32_t* devices;           /* as in jk_illumina_args (jk_pacbio_ref / jk_pacbio_hap) */
+    uint32_t n_devices;
 } jk_pacbio_args;
 
 const char* jk_last_error(void);
@@ -191,10 +207,18 @@ int jk_session_sizes(const jk_session* s, uint64_t bytes[2], uint64_t* reads, ui
 int jk_session_device_ptr(const jk_session* s, uint32_t end, const void** dptr);
 /* Copy the FASTQ image of read end e to host memory (cap >= bytes[e]). */
 int jk_session_fetch(const jk_session* s, uint32_t end, void* dst, uint64_t cap);
+/* Copy bytes [byte_off, byte_off + n) of the FASTQ image of read end e to host memory: lane windows of an image
+ * that is too large to fetch whole (the images of BASELINE configs[2..4] are 100-200 GB). */
+int jk_session_fetch_range(const jk_session* s, uint32_t end, uint64_t byte_off, uint64_t n, void* dst);
 /* Write <out_prefix>_R<e+1>.fq[.gz] for every end: FileUncomp / FileGZ / FileBGZF of src/io.h:58-295,
  * chosen by args.compress and args.comp_method.  Compression runs on the host after generation, as the
  * reference does for n_threads > 1 (src/hts.h:478-490). */
 int jk_session_write(const jk_session* s);
+/* A lane shard (lane_begin/lane_end a proper sub-range) holds only its part of the files: jk_session_write refuses
+ * it; this call writes the shard's image of read end e at byte file_offset[e] of <out_prefix>_R<e+1>.fq, creating the
+ * file if needed and never truncating it (ranks sharing a prefix write disjoint ranges; offsets = exclusive prefix of
+ * the ranks' jk_session_sizes, the count exchange of the multi-GPU design).  Uncompressed output only. */
+int jk_session_write_shard(const jk_session* s, const uint64_t file_offset[2]);
 /* Timing of the last generate(): HIP-event milliseconds on the session's stream.
  * ms[0] generator kernel(s), ms[1] scan + compaction kernels, ms[2] whole generate() (device). */
 int jk_session_timing(const jk_session* s, double ms[3]);
@@ -202,6 +226,9 @@ int jk_session_timing(const jk_session* s, double ms[3]);
 uint32_t jk_session_batches(const jk_session* s);
 /* Number of sub-seed words consumed while opening the session. */
 uint64_t jk_session_seed_words_used(const jk_session* s);
+/* Positions [begin, end) in the seed-word stream of the add_n_reads words of this shard's lanes (after the
+ * n_threads * 8 words of mt_seeds): what ranks exchange to give each other args.seed_offset_words. */
+int jk_session_shard_seed_words(const jk_session* s, uint64_t* begin, uint64_t* end);
 /* Per-lane counts, for the multi-GPU count/offset exchange: n = lane_end - lane_begin entries. */
 int jk_session_lane_bytes(const jk_session* s, uint32_t end, uint64_t* out, uint64_t n);
 void jk_session_close(jk_session* s);
@@ -211,6 +238,17 @@ void jk_split_int(uint64_t x, uint64_t n, uint64_t* out);                       
 int jk_reads_per_group(uint64_t n_reads, const double* probs, uint64_t n,         /* src/hts.h:58-103 */
                        jk_seed_source* seeds, uint64_t* out);
 void jk_alias_build(const double* probs, uint64_t n, double* Prob, uint64_t* Alias);   /* src/alias_sampler.h:68-106 */
+/* What the sessions do for `n_threads` lanes before any kernel runs (write_reads_one_filetype_, src/hts.h:334-353):
+ * split_int of the reads, mt_seeds, then per lane the filler's add_n_reads -- reference genome: reads_per_group over
+ * the chromosomes; haplotypes (hap != 0): reads_per_group over haplotype_probs, per haplotype over its chromosomes,
+ * then each read maker's own add_n_reads (which sees half the count when maker_halves, the paired Illumina case).
+ * chrom_probs: [n_haps or 1][n_chroms] chromosome sizes.  Outputs for lanes [lane_begin, lane_end) (0 = n_threads):
+ * lane_seeds [n_shard * 8], quotas [cell][lane of the shard] in reads (all ends), words3 = {seed words consumed,
+ * first and one-past-last position of the shard's add_n_reads words}.  Host only. */
+int jk_plan_lane_quotas(int32_t hap, uint32_t n_ends, int32_t maker_halves, const double* hap_probs, uint64_t n_haps,
+                        const double* chrom_probs, uint64_t n_chroms, uint64_t n_reads, uint64_t n_threads,
+                        uint64_t lane_begin, uint64_t lane_end, jk_seed_source* seeds, int32_t offset_given, uint64_t offset_words,
+                        uint32_t* lane_seeds, uint32_t* quotas, uint64_t* words3);
 int jk_hap_chrom_full(const jk_hap_set* haps, uint64_t hap, uint64_t chrom, char* out, uint64_t cap); /* src/hap_classes.cpp:80-116 (host) */
 /* pcg64 seeded from 8 words (src/pcg.h:48-85), jumped `steps` outputs ahead (engine::advance,
  * inst/include/pcg/pcg_random.hpp:419-434), then n outputs: the jump tables of jk_create_genome (host) */

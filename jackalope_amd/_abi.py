@@ -79,7 +79,9 @@ class IlluminaArgs(C.Structure):
                 ("abort_flag", C.POINTER(C.c_int32)),
                 ("lane_begin", C.c_uint64), ("lane_end", C.c_uint64),
                 ("device", C.c_int32),
-                ("max_batch_bytes", C.c_uint64)]
+                ("max_batch_bytes", C.c_uint64),
+                ("seed_offset_given", C.c_int32), ("seed_offset_words", C.c_uint64),
+                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32)]
 
 
 class PacbioArgs(C.Structure):
@@ -98,16 +100,19 @@ class PacbioArgs(C.Structure):
                 ("abort_flag", C.POINTER(C.c_int32)),
                 ("lane_begin", C.c_uint64), ("lane_end", C.c_uint64),
                 ("device", C.c_int32),
-                ("max_batch_bytes", C.c_uint64)]
+                ("max_batch_bytes", C.c_uint64),
+                ("seed_offset_given", C.c_int32), ("seed_offset_words", C.c_uint64),
+                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32)]
 
 
 # every symbol include/jackalope_hip.h declares
 EXPORTS = [
     "jk_last_error", "jk_version", "jk_illumina_ref", "jk_illumina_hap", "jk_pacbio_ref", "jk_pacbio_hap",
     "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_pacbio_ref_open", "jk_pacbio_hap_open", "jk_session_generate", "jk_session_sizes",
-    "jk_session_device_ptr", "jk_session_fetch", "jk_session_write", "jk_session_timing",
+    "jk_session_device_ptr", "jk_session_fetch", "jk_session_fetch_range", "jk_session_write", "jk_session_write_shard",
+    "jk_session_shard_seed_words", "jk_session_timing",
     "jk_session_seed_words_used", "jk_session_batches", "jk_session_lane_bytes", "jk_session_close",
-    "jk_split_int", "jk_reads_per_group", "jk_alias_build", "jk_hap_chrom_full",
+    "jk_split_int", "jk_reads_per_group", "jk_plan_lane_quotas", "jk_alias_build", "jk_hap_chrom_full",
     "jk_host_eval", "jk_dev_eval", "jk_eval_set_gamma", "jk_x87_one_minus",
     "jk_hap_builder_new", "jk_hap_builder_from", "jk_add_substitution", "jk_add_insertion", "jk_add_deletion",
     "jk_hap_builder_view", "jk_hap_builder_free",
@@ -153,6 +158,9 @@ def lib():
     L.jk_session_device_ptr.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.jk_session_fetch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
     L.jk_session_write.argtypes = [C.c_void_p]
+    L.jk_session_fetch_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.jk_session_write_shard.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.jk_session_shard_seed_words.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.jk_session_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.jk_session_lane_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
     L.jk_session_close.argtypes = [C.c_void_p]
@@ -160,6 +168,9 @@ def lib():
     L.jk_split_int.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
     L.jk_split_int.restype = None
     L.jk_reads_per_group.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(SeedSource), C.c_void_p]
+    L.jk_plan_lane_quotas.argtypes = [C.c_int32, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64,
+                                      C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(SeedSource), C.c_int32, C.c_uint64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]
     L.jk_alias_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.jk_alias_build.restype = None
     L.jk_hap_chrom_full.argtypes = [C.POINTER(HapSetView), C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]

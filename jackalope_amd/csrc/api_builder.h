@@ -19,6 +19,29 @@ int jk_reads_per_group(uint64_t n_reads, const double* probs, uint64_t n, jk_see
     });
 }
 
+// The per-lane quota planner of the sessions on its own (jk_plan.h): host only, no device needed.
+int jk_plan_lane_quotas(int32_t hap, uint32_t n_ends, int32_t maker_halves, const double* hap_probs, uint64_t n_haps,
+                        const double* chrom_probs, uint64_t n_chroms, uint64_t n_reads, uint64_t n_threads,
+                        uint64_t lane_begin, uint64_t lane_end, jk_seed_source* seeds, int32_t offset_given, uint64_t offset_words,
+                        uint32_t* lane_seeds, uint32_t* quotas, uint64_t* words3) {
+    return guarded([&] {
+        if (!seeds || !chrom_probs || n_ends == 0 || n_threads == 0) throw Error(JK_ERR_ARG, "bad argument");
+        if (lane_end == 0) lane_end = n_threads;
+        if (lane_begin > lane_end || lane_end > n_threads) throw Error(JK_ERR_ARG, "lane shard out of range");
+        std::vector<uint64_t> per_lane = split_int(n_reads / n_ends, n_threads);
+        for (uint64_t& v : per_lane) v *= n_ends;
+        QuotaModel Q;
+        Q.hap = hap != 0; Q.n_ends = n_ends; Q.maker_halves = maker_halves != 0; Q.n_haps = Q.hap ? n_haps : 1; Q.n_chroms = n_chroms;
+        if (Q.hap) Q.hap_chain = GroupChain(std::vector<double>(hap_probs, hap_probs + n_haps));
+        for (uint64_t h = 0; h < Q.n_haps; h++) Q.chrom_chain.emplace_back(std::vector<double>(chrom_probs + h * n_chroms, chrom_probs + (h + 1) * n_chroms));
+        SeedReader r{*seeds};
+        LanePlan lp = plan_lane_quotas(Q, per_lane, lane_begin, lane_end, r, offset_given != 0, offset_words);
+        if (lane_seeds) std::memcpy(lane_seeds, lp.lane_seeds.data(), lp.lane_seeds.size() * 4);
+        if (quotas) std::memcpy(quotas, lp.quotas.data(), lp.quotas.size() * 4);
+        if (words3) { words3[0] = lp.words_used; words3[1] = lp.shard_begin_word; words3[2] = lp.shard_end_word; }
+    });
+}
+
 void jk_alias_build(const double* probs, uint64_t n, double* Prob, uint64_t* Alias) {
     AliasTable t = alias_build(std::vector<double>(probs, probs + n));
     for (uint64_t i = 0; i < n; i++) { Prob[i] = t.prob[i]; Alias[i] = t.alias[i]; }

@@ -112,17 +112,6 @@ static std::vector<uint64_t> plan_lanes(jk_session& s, uint64_t n_threads, uint6
     return per_lane;
 }
 
-// mt_seeds (src/pcg.h:37-46): 8 words per lane for ALL lanes, in lane order; keep this shard's.
-static std::vector<uint32_t> take_lane_seeds(jk_session& s, SeedReader& seeds) {
-    std::vector<uint32_t> lane_seeds(s.n_shard * 8);
-    uint32_t w[8];
-    for (uint64_t t = 0; t < s.n_lanes_total; t++) {
-        seeds.take8(w);
-        if (t >= s.lane_begin && t < s.lane_end) std::memcpy(&lane_seeds[(t - s.lane_begin) * 8], w, sizeof(w));
-    }
-    return lane_seeds;
-}
-
 // Pools: tiles of 64 lanes (one wave), every lane of a tile gets the capacity of the tile's largest
 // quota of maximal records; a batch is a run of whole tiles.  Then all device buffers.
 // lane_cap[l] = pool bytes lane l may need.  Plans batches/tiles and allocates everything that does not
@@ -132,7 +121,7 @@ static std::vector<uint32_t> take_lane_seeds(jk_session& s, SeedReader& seeds) {
 // refuses to write past it (JK_KERR_IMAGE_FULL).
 static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint64_t lanes_per_batch,
                                   const std::vector<uint64_t>& lane_cap, const std::vector<uint64_t>& lane_reads,
-                                  const std::vector<uint32_t>& lane_seeds, const std::vector<uint32_t>& quotas,
+                                  const std::vector<uint32_t>& lane_seeds, const ZeroArray<uint32_t>& quotas,
                                   uint64_t image_hint = 0) {
     uint64_t max_batch_lanes = lanes_per_batch;
     if (const char* e = std::getenv("JK_BATCH_LANES")) { const long long v = std::atoll(e); if (v >= 64) max_batch_lanes = (uint64_t)v / 64 * 64; }
@@ -179,9 +168,23 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     }
     if (image_hint) out_cap = std::min<uint64_t>(out_cap, image_hint + image_hint / 8 + (64ULL << 20));
     s.out_cap = out_cap;
+    {   // say what does not fit before hipMalloc does (a tile's pools are 64 x its largest lane: few lanes with many
+        // reads each need far more pool than their FASTQ)
+        size_t free_b = 0, total_b = 0;
+        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t sets = s.batches.size() > 1 ? 2 : 1;
+        const uint64_t image = s.streaming ? 0 : out_cap;
+        const uint64_t need = (sets * (max_pool + 64 + CP_SLACK) + image + 64) * s.n_ends + s.n_shard * 64;
+        if (need > free_b)
+            throw Error(JK_ERR_DEVICE, "this run needs " + std::to_string(need >> 20) + " MiB of device memory (" +
+                        std::to_string((sets * max_pool * s.n_ends) >> 20) + " MiB of read pools for " + std::to_string(max_lanes) +
+                        " lanes per launch, " + std::to_string((image * s.n_ends) >> 20) + " MiB of FASTQ image) and " +
+                        std::to_string(free_b >> 20) + " MiB are free: raise n_threads (more, shorter lanes), lower max_batch_bytes, "
+                        "or split the job over more GPUs / calls");
+    }
     s.d_seeds.upload(lane_seeds);
     s.d_lane_reads.upload(lane_reads);
-    s.d_chrom_reads.upload(quotas);
+    s.d_chrom_reads.upload(quotas.data(), quotas.size());
     s.d_pool_off.upload(pool_off);
     for (uint32_t e = 0; e < s.n_ends; e++) {
         s.d_pool[0][e].alloc(max_pool + 64 + CP_SLACK);
@@ -224,12 +227,17 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
 
 static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const std::vector<uint64_t>& lane_reads,
                                  uint64_t rec_max, const std::vector<uint32_t>& lane_seeds,
-                                 const std::vector<uint32_t>& quotas) {
+                                 const ZeroArray<uint32_t>& quotas) {
     // A batch is one generator launch.  Default: 2^18 lanes = one 1024-thread workgroup on each of the
     // 256 CUs, so every launch is a single full wave of workgroups and the pool compaction of batch b
     // (HBM-bound, second stream) runs under the generator of batch b+1 (ALU-bound).
     std::vector<uint64_t> lane_cap(s.n_shard);
     for (uint64_t l = 0; l < s.n_shard; l++) lane_cap[l] = (lane_reads[l] / s.n_ends) * rec_max;
+    // a lane's position in its pool is a 32-bit byte offset in the generator and the compaction
+    if (!lane_cap.empty() && *std::max_element(lane_cap.begin(), lane_cap.end()) >= (1ULL << 32))
+        throw Error(JK_ERR_UNSUPPORTED, "a lane would write 4 GiB or more of FASTQ per read end (" +
+                    std::to_string(lane_reads.empty() ? 0 : lane_reads[0] / s.n_ends) + " reads of up to " + std::to_string(rec_max) +
+                    " bytes): raise n_threads -- on the GPU n_threads is the number of generator lanes, 2^16..2^20 per device");
     const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, 1ULL << 18, lane_cap, lane_reads, lane_seeds, quotas);
     const IlluminaPacked packed = pack_illumina_tables(s.tables);
     s.d_tab.upload(packed.tab);
@@ -308,29 +316,17 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
     if (frag_lb < std::max<uint64_t>(barcode.size(), 1))
         throw Error(JK_ERR_UNSUPPORTED, "fragments shorter than the barcode (or empty) are not implemented on the GPU path");
 
-    // ---- lanes, quotas, seeds: same order of seed consumption as src/hts.h:334-353
+    // ---- lanes, quotas, seeds: same order of seed consumption as src/hts.h:334-353 (mt_seeds, then per lane
+    // IlluminaOneGenome::add_n_reads, src/hts_illumina.h:410-418); see jk_plan.h
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, a.n_reads);
-    const uint64_t T = s.n_lanes_total;
-    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
-    std::vector<uint64_t> lane_reads(s.n_shard);
-    std::vector<uint32_t> chrom_reads((size_t)s.n_chroms * s.n_shard, 0);
-    const std::vector<std::vector<double>> chrom_probs(1, std::vector<double>(g.chrom_lens, g.chrom_lens + g.n_chroms));
-    DeferredSplits splits(&chrom_probs, chrom_reads.data(), s.n_shard, s.paired ? 2u : 1u);
-    for (uint64_t t = 0; t < T; t++) {
-        // IlluminaOneGenome::add_n_reads (src/hts_illumina.h:410-418)
-        uint64_t n = per_lane[t];
-        if (s.paired) n /= 2;
-        const bool mine = t >= s.lane_begin && t < s.lane_end;
-        if (!mine) {                       // only keep the seed stream in step
-            if (n > 0) { uint32_t w[8]; seeds.take8(w); }
-            continue;
-        }
-        const uint64_t l = t - s.lane_begin;
-        lane_reads[l] = per_lane[t];
-        splits.add(n, seeds, 0, 0, l);
-    }
-    splits.flush();
-    s.seed_words_used = seeds.pos;
+    QuotaModel Q;
+    Q.n_ends = s.n_ends; Q.n_chroms = g.n_chroms;
+    Q.chrom_chain.emplace_back(std::vector<double>(g.chrom_lens, g.chrom_lens + g.n_chroms));
+    LanePlan lp = plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, a.seed_offset_given != 0, a.seed_offset_words);
+    s.seed_words_used = lp.words_used; s.shard_seed_begin = lp.shard_begin_word; s.shard_seed_end = lp.shard_end_word;
+    const std::vector<uint64_t>& lane_reads = lp.lane_reads;
+    const std::vector<uint32_t>& lane_seeds = lp.lane_seeds;
+    const ZeroArray<uint32_t>& chrom_reads = lp.quotas;
 
     IlluminaKernelParams& P = s.kp;
     P.bc_len = (uint32_t)barcode.size();
@@ -474,33 +470,21 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
     // ---- lanes, quotas, seeds.  IlluminaHaplotypes::add_n_reads (src/hts_illumina.h:620-644) per lane:
     // reads_per_group over haplotypes, then per haplotype reads_per_group over its chromosomes, then
     // each read maker's own add_n_reads (halves the pair count again when paired; its result is never
-    // read by the haplotype path, but it consumes 8 seed words when it has reads).
+    // read by the haplotype path, but it consumes 8 seed words when it has reads).  See jk_plan.h.
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, n_reads);
-    const uint64_t T = s.n_lanes_total;
-    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
-    std::vector<uint64_t> lane_reads(s.n_shard);
-    std::vector<uint32_t> vc((size_t)n_cells * s.n_shard, 0);
-    std::vector<std::vector<double>> chrom_probs(nh, std::vector<double>(nc));
-    for (uint64_t h = 0; h < nh; h++) for (uint64_t c = 0; c < nc; c++) chrom_probs[h][c] = (double)cell_size[h * nc + c];
-    DeferredSplits splits(&chrom_probs, vc.data(), s.n_shard, s.paired ? 2u : 1u);
-    for (uint64_t t = 0; t < T; t++) {
-        uint64_t n = per_lane[t];
-        if (s.paired) n /= 2;
-        const bool mine = t >= s.lane_begin && t < s.lane_end;
-        std::vector<uint64_t> hap_reads = reads_per_group(n, hap_probs, seeds);
-        for (uint64_t h = 0; h < nh; h++) {
-            if (mine) splits.add(hap_reads[h], seeds, (uint32_t)h, h * nc, t - s.lane_begin);
-            else if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }
-        }
-        for (uint64_t h = 0; h < nh; h++) {
-            uint64_t m = hap_reads[h];
-            if (s.paired) m /= 2;
-            if (m > 0) { uint32_t w[8]; seeds.take8(w); }
-        }
-        if (mine) lane_reads[t - s.lane_begin] = per_lane[t];
+    QuotaModel Q;
+    Q.hap = true; Q.n_ends = s.n_ends; Q.maker_halves = s.paired; Q.n_haps = nh; Q.n_chroms = nc;
+    Q.hap_chain = GroupChain(hap_probs);
+    for (uint64_t h = 0; h < nh; h++) {
+        std::vector<double> cp(nc);
+        for (uint64_t c = 0; c < nc; c++) cp[c] = (double)cell_size[h * nc + c];
+        Q.chrom_chain.emplace_back(cp);
     }
-    splits.flush();
-    s.seed_words_used = seeds.pos;
+    LanePlan lp = plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, a.seed_offset_given != 0, a.seed_offset_words);
+    s.seed_words_used = lp.words_used; s.shard_seed_begin = lp.shard_begin_word; s.shard_seed_end = lp.shard_end_word;
+    const std::vector<uint64_t>& lane_reads = lp.lane_reads;
+    const std::vector<uint32_t>& lane_seeds = lp.lane_seeds;
+    const ZeroArray<uint32_t>& vc = lp.quotas;
 
     IlluminaKernelParams& P = s.kp;
     P.bc_len = 0;

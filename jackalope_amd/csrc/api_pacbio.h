@@ -126,7 +126,7 @@ static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a
 
 static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioHostModel& M, size_t max_hdr, uint64_t max_chrom,
                           const std::vector<uint64_t>& lane_reads, const std::vector<uint32_t>& lane_seeds,
-                          const std::vector<uint32_t>& quotas) {
+                          const ZeroArray<uint32_t>& quotas) {
     // pools: sized for reads of length len_hi; the kernel checks before every record and the session retries
     // with a larger scale if a lane ran out (s.pool_scale)
     const uint64_t rec = max_hdr + n_digits(max_chrom) + 3 + 2 * M.len_hi + 8;
@@ -186,25 +186,15 @@ static void open_pacbio_ref(jk_session& s, const jk_ref_genome& g, const jk_pacb
     upload_headers(s, hdrs, max_hdr);
     // lanes, quotas, seeds (src/hts.h:334-353 with n_read_ends = 1; PacBioOneGenome::add_n_reads, hts_pacbio.h:499-503)
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, a.n_reads);
-    const uint64_t T = s.n_lanes_total;
-    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
-    std::vector<uint64_t> lane_reads(s.n_shard);
-    std::vector<uint32_t> chrom_reads((size_t)s.n_chroms * s.n_shard, 0);
-    const std::vector<std::vector<double>> chrom_probs(1, std::vector<double>(g.chrom_lens, g.chrom_lens + g.n_chroms));
-    DeferredSplits splits(&chrom_probs, chrom_reads.data(), s.n_shard, 1u);
-    for (uint64_t t = 0; t < T; t++) {
-        const uint64_t n = per_lane[t];
-        const bool mine = t >= s.lane_begin && t < s.lane_end;
-        if (!mine) { if (n > 0) { uint32_t w[8]; seeds.take8(w); } continue; }
-        const uint64_t l = t - s.lane_begin;
-        lane_reads[l] = n;
-        splits.add(n, seeds, 0, 0, l);
-    }
-    splits.flush();
-    s.seed_words_used = seeds.pos;
+    QuotaModel Q;
+    Q.n_ends = 1; Q.n_chroms = g.n_chroms;
+    Q.chrom_chain.emplace_back(std::vector<double>(g.chrom_lens, g.chrom_lens + g.n_chroms));
+    LanePlan lp = plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, a.seed_offset_given != 0, a.seed_offset_words);
+    s.seed_words_used = lp.words_used; s.shard_seed_begin = lp.shard_begin_word; s.shard_seed_end = lp.shard_end_word;
+    std::shared_ptr<LanePlan> plan = std::make_shared<LanePlan>(std::move(lp));
     const uint64_t mbb = a.max_batch_bytes;
     jk_session* sp = &s;
-    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, lane_reads, lane_seeds, chrom_reads); };
+    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, plan->lane_reads, plan->lane_seeds, plan->quotas); };
     s.replan();
 }
 
@@ -232,30 +222,21 @@ static void open_pacbio_hap(jk_session& s, const jk_hap_set& hs, const jk_pacbio
     upload_headers(s, hdrs, max_hdr);
     // PacBioHaplotypes::add_n_reads (src/hts_pacbio.h:683-700)
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, n_reads);
-    const uint64_t T = s.n_lanes_total;
-    std::vector<uint32_t> lane_seeds = take_lane_seeds(s, seeds);
-    std::vector<uint64_t> lane_reads(s.n_shard);
-    std::vector<uint32_t> vc((size_t)n_cells * s.n_shard, 0);
-    std::vector<std::vector<double>> chrom_probs(nh, std::vector<double>(nc));
-    for (uint64_t h = 0; h < nh; h++) for (uint64_t c = 0; c < nc; c++) chrom_probs[h][c] = (double)cell_size[h * nc + c];
-    DeferredSplits splits(&chrom_probs, vc.data(), s.n_shard, 1u);
-    for (uint64_t t = 0; t < T; t++) {
-        const uint64_t n = per_lane[t];
-        const bool mine = t >= s.lane_begin && t < s.lane_end;
-        std::vector<uint64_t> hap_reads = reads_per_group(n, hap_probs, seeds);
-        for (uint64_t h = 0; h < nh; h++) {
-            if (mine) splits.add(hap_reads[h], seeds, (uint32_t)h, h * nc, t - s.lane_begin);
-            else if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }
-        }
-        for (uint64_t h = 0; h < nh; h++) if (hap_reads[h] > 0) { uint32_t w[8]; seeds.take8(w); }   // read_makers[h].add_n_reads
-        if (mine) lane_reads[t - s.lane_begin] = n;
+    QuotaModel Q;
+    Q.hap = true; Q.n_ends = 1; Q.maker_halves = false; Q.n_haps = nh; Q.n_chroms = nc;
+    Q.hap_chain = GroupChain(hap_probs);
+    for (uint64_t h = 0; h < nh; h++) {
+        std::vector<double> cp(nc);
+        for (uint64_t c = 0; c < nc; c++) cp[c] = (double)cell_size[h * nc + c];
+        Q.chrom_chain.emplace_back(cp);
     }
-    splits.flush();
-    s.seed_words_used = seeds.pos;
+    LanePlan lp = plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, a.seed_offset_given != 0, a.seed_offset_words);
+    s.seed_words_used = lp.words_used; s.shard_seed_begin = lp.shard_begin_word; s.shard_seed_end = lp.shard_end_word;
+    std::shared_ptr<LanePlan> plan = std::make_shared<LanePlan>(std::move(lp));
     set_hap_params(s, s.kpb.h, (uint32_t)nh);
     const uint64_t mbb = a.max_batch_bytes;
     jk_session* sp = &s;
-    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, lane_reads, lane_seeds, vc); };
+    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, plan->lane_reads, plan->lane_seeds, plan->quotas); };
     s.replan();
 }
 

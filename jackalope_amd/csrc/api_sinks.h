@@ -147,8 +147,34 @@ static void stream_to_host(const uint8_t* d_src, uint64_t n, size_t piece, Sink&
     }
 }
 
+// A lane shard's image at its place in the shared file (see jk_session_write_shard).
+static void write_shard(const jk_session& s, const uint64_t* file_offset) {
+    if (!s.generated) throw Error(JK_ERR_ARG, "jk_session_write_shard before jk_session_generate");
+    if (s.compress > 0) throw Error(JK_ERR_UNSUPPORTED, "lane shards write uncompressed FASTQ only (compress the assembled file, or give each rank its own out_prefix)");
+    for (uint32_t e = 0; e < s.n_ends; e++) {
+        const std::string fn = s.out_prefix + "_R" + std::to_string(e + 1) + ".fq";
+        struct Fd { int fd = -1; ~Fd() { if (fd >= 0) ::close(fd); } } F;
+        F.fd = ::open(fn.c_str(), O_WRONLY | O_CREAT, 0644);
+        if (F.fd < 0) throw Error(JK_ERR_IO, "Unable to open file " + fn + ".\n");
+        uint64_t at = file_offset[e];
+        stream_to_host(s.d_out[e].as<uint8_t>(), s.bytes[e], BGZF_IN * 1024, [&](const uint8_t* p, size_t n) {
+            while (n) {
+                const ssize_t w = ::pwrite(F.fd, p, n, (off_t)at);
+                if (w < 0) { if (errno == EINTR) continue; throw Error(JK_ERR_IO, "write to " + fn + " failed"); }
+                p += w; n -= (size_t)w; at += (uint64_t)w;
+            }
+        });
+        const int fd = F.fd; F.fd = -1;
+        if (::close(fd) != 0) throw Error(JK_ERR_IO, "error closing " + fn);
+    }
+}
+
 static void write_files(const jk_session& s) {
     if (!s.generated) throw Error(JK_ERR_ARG, "jk_session_write before jk_session_generate");
+    if (s.n_shard != s.n_lanes_total)
+        throw Error(JK_ERR_UNSUPPORTED, "this session holds lanes " + std::to_string(s.lane_begin) + ".." + std::to_string(s.lane_end) + " of " +
+                    std::to_string(s.n_lanes_total) + ": writing it as the whole file would drop the other lanes' reads -- use "
+                    "jk_session_write_shard with the byte offsets from the ranks' jk_session_sizes");
     const size_t CH = BGZF_IN * 1024;                     // 66.8 MB, a whole number of BGZF blocks
     const unsigned n_thr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     for (uint32_t e = 0; e < s.n_ends; e++) {

@@ -32,6 +32,7 @@
 #include "../../include/jackalope_hip.h"
 #include "jk_haps.h"
 #include "jk_host.h"
+#include "jk_plan.h"
 #include "jk_illumina_kernel.h"
 #include "jk_math2.h"
 #include "jk_nmath.h"
@@ -190,6 +191,32 @@ int jk_session_fetch(const jk_session* s, uint32_t end, void* dst, uint64_t cap)
         if (cap < s->bytes[end]) throw Error(JK_ERR_ARG, "destination too small");
         JK_HIP(hipSetDevice(s->device));
         if (s->bytes[end]) JK_HIP(hipMemcpy(dst, s->d_out[end].p, s->bytes[end], hipMemcpyDeviceToHost));
+    });
+}
+
+int jk_session_fetch_range(const jk_session* s, uint32_t end, uint64_t byte_off, uint64_t n, void* dst) {
+    return guarded([&] {
+        if (!s || !s->generated || end >= s->n_ends) throw Error(JK_ERR_ARG, "bad session/end");
+        if (byte_off > s->bytes[end] || n > s->bytes[end] - byte_off) throw Error(JK_ERR_ARG, "range outside the FASTQ image");
+        if (n && !dst) throw Error(JK_ERR_ARG, "NULL destination");
+        JK_HIP(hipSetDevice(s->device));
+        if (n) JK_HIP(hipMemcpy(dst, s->d_out[end].as<uint8_t>() + byte_off, n, hipMemcpyDeviceToHost));
+    });
+}
+
+int jk_session_write_shard(const jk_session* s, const uint64_t file_offset[2]) {
+    return guarded([&] {
+        if (!s || !file_offset) throw Error(JK_ERR_ARG, "NULL argument");
+        JK_HIP(hipSetDevice(s->device));
+        write_shard(*s, file_offset);
+    });
+}
+
+int jk_session_shard_seed_words(const jk_session* s, uint64_t* begin, uint64_t* end) {
+    return guarded([&] {
+        if (!s) throw Error(JK_ERR_ARG, "NULL session");
+        if (begin) *begin = s->shard_seed_begin;
+        if (end) *end = s->shard_seed_end;
     });
 }
 

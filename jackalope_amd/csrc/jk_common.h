@@ -33,9 +33,10 @@ struct DevBuf {
         n = bytes;
     }
     template <typename T> T* as() const { return static_cast<T*>(p); }
-    template <typename T> void upload(const std::vector<T>& v) {
-        alloc(v.size() * sizeof(T));
-        if (!v.empty()) JK_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    template <typename T> void upload(const std::vector<T>& v) { upload(v.data(), v.size()); }
+    template <typename T> void upload(const T* v, size_t count) {
+        alloc(count * sizeof(T));
+        if (count) JK_HIP(hipMemcpy(p, v, count * sizeof(T), hipMemcpyHostToDevice));
     }
 };
 

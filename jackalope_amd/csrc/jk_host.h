@@ -82,26 +82,80 @@ inline std::vector<uint64_t> split_int(uint64_t x, uint64_t n) {
     return out;
 }
 
+// The probabilities reads_per_group() ends up using for its binomials: the loop
+//     probs /= accumulate(probs); for g: ...; rest = 1 - probs[g]; probs[j > g] /= rest
+// restated once (same operations in the same order), since nothing in it depends on the draws.
+struct GroupChain {
+    size_t G = 0;
+    std::vector<double> p;        // [G-1] probability of group g's binomial
+    std::vector<uint8_t> kind;    // [G-1] 0 = draw, 1 = skipped (probability 0), 2 = takes all remaining reads
+    explicit GroupChain(std::vector<double> probs = {}) {
+        G = probs.size();
+        if (G == 0) return;
+        const double total = std::accumulate(probs.begin(), probs.end(), 0.0);
+        for (double& v : probs) v /= total;
+        p.assign(G - 1, 0.0); kind.assign(G - 1, 1);
+        for (size_t g = 0; g + 1 < G; g++) {
+            if (probs[g] >= 1) { kind[g] = 2; break; }
+            if (probs[g] == 0) continue;
+            kind[g] = 0; p[g] = probs[g];
+            const double rest = 1 - probs[g];
+            for (size_t j = g + 1; j < G; j++) probs[j] /= rest;
+        }
+    }
+};
+
+// std::binomial_distribution<uint64_t>(t, p)(eng) as libstdc++ 11 computes it (random.tcc:1469-1680):
+// t * min(p, 1-p) >= 8 uses the distribution object (rejection algorithm, stateful normal deviate);
+// below that the waiting-time algorithm, restated: sum of -log(1 - u) / (t - x) until it exceeds -log(1 - p12).
+struct BinomDraw {
+    std::binomial_distribution<uint64_t> dist{1, 0.5};
+    uint64_t operator()(HostPcg& eng, uint64_t t, double p) {
+        const double p12 = p <= 0.5 ? p : 1.0 - p;
+        if (static_cast<double>(t) * p12 >= 8) {
+            dist.param(std::binomial_distribution<uint64_t>::param_type(t, p));
+            return dist(eng);
+        }
+        const double q = -std::log(1 - p12);
+        uint64_t x = 0;
+        double sum = 0.0;
+        do {
+            if (t == x) { x++; break; }             // (returns x: undone by the -1 below)
+            const double e = -std::log(1.0 - jk_canonical(eng()));
+            sum += e / static_cast<double>(t - x);
+            x += 1;
+        } while (sum <= q);
+        uint64_t ret = x - 1;
+        if (p12 != p) ret = t - ret;
+        return ret;
+    }
+};
+
+// reads_per_group (src/hts.h:58-103) with the chain precomputed; out[g * out_stride], g < G.
+template <typename Store>
+inline void split_with_chain(uint64_t n_reads, const GroupChain& ch, const uint32_t* w, BinomDraw& bd, Store store) {
+    const size_t G = ch.G;          // (the destination starts zeroed: only non-zero groups are stored)
+    if (G == 0 || n_reads == 0) return;
+    HostPcg eng{jk_pcg_seed(w)};
+    bd.dist.reset();                                  // a fresh distribution object per call, as in the reference
+    for (size_t g = 0; g + 1 < G; g++) {
+        if (ch.kind[g] == 2) { store(g, n_reads); return; }
+        if (ch.kind[g] == 1) continue;
+        const uint64_t k = bd(eng, n_reads, ch.p[g]);
+        if (k) store(g, k);
+        n_reads -= k;
+        if (n_reads == 0) break;
+    }
+    if (n_reads) store(G - 1, n_reads);
+}
+
 // Sequential conditional binomials over groups (reference: src/hts.h:58-103) from a fresh engine seeded
 // with the 8 words `w`.
-inline std::vector<uint64_t> reads_per_group_w(uint64_t n_reads, std::vector<double> probs, const uint32_t* w) {
-    const size_t G = probs.size();
-    std::vector<uint64_t> out(G, 0);
-    HostPcg eng{jk_pcg_seed(w)};
-    double total = std::accumulate(probs.begin(), probs.end(), 0.0);
-    for (double& p : probs) p /= total;
-    std::binomial_distribution<uint64_t> binom(n_reads, 0.5);
-    for (size_t g = 0; g + 1 < G; g++) {
-        if (probs[g] >= 1) { out[g] = n_reads; return out; }
-        if (probs[g] == 0) continue;
-        binom.param(std::binomial_distribution<uint64_t>::param_type(n_reads, probs[g]));
-        out[g] = binom(eng);
-        n_reads -= out[g];
-        if (n_reads == 0) break;
-        const double rest = 1 - probs[g];
-        for (size_t j = g + 1; j < G; j++) probs[j] /= rest;
-    }
-    out[G - 1] = n_reads;
+inline std::vector<uint64_t> reads_per_group_w(uint64_t n_reads, const std::vector<double>& probs, const uint32_t* w) {
+    std::vector<uint64_t> out(probs.size(), 0);
+    GroupChain ch(probs);
+    BinomDraw bd;
+    split_with_chain(n_reads, ch, w, bd, [&](size_t g, uint64_t v) { out[g] = v; });
     return out;
 }
 // ... taking the words itself.  Consumes 8 seed words whenever n_reads > 0 and there is at least one
@@ -112,45 +166,6 @@ inline std::vector<uint64_t> reads_per_group(uint64_t n_reads, const std::vector
     seeds.take8(w);
     return reads_per_group_w(n_reads, probs, w);
 }
-
-// The per-lane chromosome splits of a run with ~10^6 lanes are ~10^8 binomial draws; one reference thread
-// does its own, here one host would do them all.  The seed words are still taken in the reference's order
-// on the calling thread (R's RNG is sequential); the binomial chains, which only depend on their 8 words,
-// run on host threads.  out[(cell0 + c) * stride + lane] = reads of group c, times `mult`.
-struct DeferredSplits {
-    struct Task { uint64_t n; uint32_t w[8]; uint32_t probs_id; uint64_t cell0, lane; };
-    const std::vector<std::vector<double>>* probs;
-    uint32_t* out; size_t stride; uint32_t mult;
-    std::vector<Task> tasks;
-    DeferredSplits(const std::vector<std::vector<double>>* p, uint32_t* o, size_t st, uint32_t m) : probs(p), out(o), stride(st), mult(m) {}
-    void add(uint64_t n, SeedReader& seeds, uint32_t probs_id, uint64_t cell0, uint64_t lane) {
-        if (n == 0 || (*probs)[probs_id].empty()) return;        // reads_per_group: nothing drawn, nothing consumed
-        Task t; t.n = n; t.probs_id = probs_id; t.cell0 = cell0; t.lane = lane;
-        seeds.take8(t.w);
-        tasks.push_back(t);
-        if (tasks.size() >= (1u << 16)) flush();
-    }
-    void flush() {
-        const size_t n = tasks.size();
-        if (n == 0) return;
-        const unsigned hw = std::thread::hardware_concurrency();
-        const size_t n_thr = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)32, n / 256 + 1}));
-        auto work = [&](size_t a, size_t b) {
-            for (size_t i = a; i < b; i++) {
-                const Task& t = tasks[i];
-                const std::vector<uint64_t> cr = reads_per_group_w(t.n, (*probs)[t.probs_id], t.w);
-                for (size_t c = 0; c < cr.size(); c++) out[(t.cell0 + c) * stride + t.lane] = (uint32_t)(cr[c] * mult);
-            }
-        };
-        if (n_thr == 1) work(0, n);
-        else {
-            std::vector<std::thread> pool;
-            for (size_t k = 0; k < n_thr; k++) pool.emplace_back(work, n * k / n_thr, n * (k + 1) / n_thr);
-            for (std::thread& th : pool) th.join();
-        }
-        tasks.clear();
-    }
-};
 
 struct AliasTable {
     std::vector<double> prob;

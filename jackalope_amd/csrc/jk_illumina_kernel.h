@@ -460,7 +460,8 @@ illumina_kernel(IlluminaKernelParams P) {
         bool reverse = jk_runif_lt_half(rng());
 #pragma unroll
         for (uint32_t i = 0; i < NE; i++) {
-            const uint32_t sp = space[i], n_out = out_len[i], ev = evalid[i];
+            const uint32_t sp = space[i], n_out = out_len[i];
+            uint32_t ev = evalid[i];
             const uint32_t ev_any = (ev | (ev >> 16)) & 0xffffu;      // words with any event
             const uint64_t cspace = (uint64_t)sp - bc;
             uint64_t start;
@@ -471,14 +472,22 @@ illumina_kernel(IlluminaKernelParams P) {
             if (ev & 0xffffu) {
                 for (int w = (int)W - 1; w >= 0; w--) {
                     if (!((ev >> w) & 1u)) continue;
-                    uint64_t rest = *evaddr(i, 0, w), b0 = 0, b1 = 0;
+                    uint64_t rest = *evaddr(i, 0, w), b0 = 0, b1 = 0, nul = 0;
                     while (rest) {
                         const int bit = 63 - jk_clz64(rest);
                         rest &= ~(1ULL << bit);
-                        const uint64_t b = jk_runif_index(rng(), 4) & 3u;   // index 4 needs x == 2^64-1
-                        b0 |= (b & 1u) << bit; b1 |= (b >> 1) << bit;
+                        // index 4 needs x == 2^64-1 (2^-64 per insertion): the reference then inserts "TCAG"[4], the
+                        // string's NUL, which fill_read_qual turns into 'N'.  Kept as "insertion AND deletion" at the
+                        // same position, a combination sample_indels never produces.
+                        const uint64_t b = jk_runif_index(rng(), 4);
+                        b0 |= (b & 1u) << bit; b1 |= ((b >> 1) & 1u) << bit; nul |= (b >> 2) << bit;
                     }
                     *evaddr(i, 2, w) = b0; *evaddr(i, 3, w) = b1;
+                    if (nul) {
+                        uint64_t* a = evaddr(i, 1, w);
+                        *a = (((ev >> (16 + w)) & 1u) ? *a : 0ULL) | nul;
+                        ev |= 1u << (16 + w);
+                    }
                 }
             }
 
@@ -812,7 +821,8 @@ illumina_kernel(IlluminaKernelParams P) {
                     } else {
                         for (;;) {
                             const uint32_t w = pp >> 6, bit = pp & 63u;
-                            const bool deleted = w < W && ((ev >> (16 + w)) & 1u) && ((*evaddr(i, 1, w) >> bit) & 1ULL);
+                            const bool deleted = w < W && ((ev >> (16 + w)) & 1u) && ((*evaddr(i, 1, w) >> bit) & 1ULL) &&
+                                                 !(((ev >> w) & 1u) && ((*evaddr(i, 0, w) >> bit) & 1ULL));     // (both bits: a NUL insertion)
                             if (!deleted) break;
                             pp++;
                         }
@@ -821,6 +831,7 @@ illumina_kernel(IlluminaKernelParams P) {
                         if (w < W && ((ev >> w) & 1u) && ((*evaddr(i, 0, w) >> bit) & 1ULL)) {
                             pending = true;
                             pend_base = (uint32_t)((*evaddr(i, 2, w) >> bit) & 1ULL) | ((uint32_t)((*evaddr(i, 3, w) >> bit) & 1ULL) << 1);
+                            if (((ev >> (16 + w)) & 1u) && ((*evaddr(i, 1, w) >> bit) & 1ULL)) pend_base = 4u;      // inserted NUL: not TCAG
                         }
                         pp++;
                     }

@@ -32,6 +32,7 @@ struct jk_session {
     bool bgzip = true;         // comp_method: "bgzip" (BGZF blocks) or "gzip"
     bool host_deflate = false; // comp_method "bgzip-host": BGZF blocks deflated by zlib on the host at level `compress`
     bool pacbio = false;
+    bool streaming = false;    // batches' images go to the sink as they complete (one-shot entry points); no resident image
     PacbioKernelParams kpb{};
     DevBuf d_len_thresh, d_len_alias, d_lens, d_thr_tab, d_pass_tab, d_ev2, d_pb_hist;
     uint32_t ev_words = 0;
@@ -54,7 +55,7 @@ struct jk_session {
     uint64_t reads_made = 0;
     double ms[3] = {0, 0, 0};
     bool generated = false;
-    uint64_t seed_words_used = 0;
+    uint64_t seed_words_used = 0, shard_seed_begin = 0, shard_seed_end = 0;
     const volatile int32_t* abort_flag = nullptr;
     std::vector<hipEvent_t> events;       // [0] start, [1+2b] / [2+2b] around generator b, last = end
     std::vector<hipEvent_t> gen_done, cp_done;   // per batch, for the two-stream hand-off

@@ -106,6 +106,21 @@ class IlluminaSession:
         _abi.check(_abi.lib().jk_session_fetch(self._h, end, out.ctypes.data, out.size))
         return out.tobytes()
 
+    def fetch_range(self, end, byte_off, n):
+        """Bytes [byte_off, byte_off + n) of the image of read end `end` (jk_session_fetch_range)."""
+        out = np.empty(int(n), dtype=np.uint8)
+        _abi.check(_abi.lib().jk_session_fetch_range(self._h, end, int(byte_off), int(n), out.ctypes.data))
+        return out.tobytes()
+
+    def write_shard(self, file_offsets):
+        off = (C.c_uint64 * 2)(*([int(x) for x in file_offsets] + [0])[:2])
+        _abi.check(_abi.lib().jk_session_write_shard(self._h, off))
+
+    def shard_seed_words(self):
+        b, e = C.c_uint64(), C.c_uint64()
+        _abi.check(_abi.lib().jk_session_shard_seed_words(self._h, C.byref(b), C.byref(e)))
+        return int(b.value), int(e.value)
+
     def device_ptr(self, end):
         p = C.c_void_p()
         _abi.check(_abi.lib().jk_session_device_ptr(self._h, end, C.byref(p)))

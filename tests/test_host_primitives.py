@@ -123,6 +123,46 @@ def test_split_int_and_reads_per_group(O, built, ja):
             assert words.size - src.n_words == used.value == (8 if n_reads > 0 else 0)
 
 
+def test_reads_per_group_fast_paths(O, built, ja):
+    """The library precomputes reads_per_group's probability chain and restates libstdc++'s waiting-time binomial
+    (t*p < 8) inline (csrc/jk_host.h: GroupChain, BinomDraw); the oracle calls std::binomial_distribution for every
+    draw as the reference does (src/hts.h:58-103).  Random splits across both binomial branches, p > 0.5, zero and
+    all-mass groups."""
+    L = _abi.lib()
+    rng = np.random.default_rng(2024)
+    for case in range(4000):
+        G = int(rng.integers(1, 31))
+        kind = case % 5
+        if kind == 0:
+            probs = rng.random(G)
+        elif kind == 1:
+            probs = rng.random(G) ** 6 * 1e9                       # very uneven: p > 0.5 and tiny p
+        elif kind == 2:
+            probs = rng.random(G) * (rng.random(G) < 0.5)          # zeros
+            if probs.sum() == 0:
+                probs[-1] = 1.0
+        elif kind == 3:
+            probs = np.zeros(G)
+            probs[int(rng.integers(0, G))] = 3.0                   # one group holds all the mass
+        else:
+            probs = np.full(G, 125e6) + rng.integers(-3, 4, size=G)   # chromosome sizes of configs[2]
+        n_reads = int([rng.integers(1, 40), rng.integers(1, 400), rng.integers(1, 10 ** 5), rng.integers(1, 10 ** 10)][case % 4])
+        words = ja.seed_words(case, 16)
+        out1, out2 = np.zeros(G, dtype=np.uint64), np.zeros(G, dtype=np.uint64)
+        src = _abi.SeedSource()
+        src.words = words.ctypes.data_as(C.POINTER(C.c_uint32))
+        src.n_words = words.size
+        probs = np.ascontiguousarray(probs, dtype=np.float64)
+        _abi.check(L.jk_reads_per_group(n_reads, probs.ctypes.data, G, C.byref(src), out1.ctypes.data))
+        used = C.c_uint64()
+        rc = O.lib().orc_reads_per_group(C.c_uint64(n_reads), probs.ctypes.data_as(C.c_void_p), C.c_uint64(G),
+                                         words.ctypes.data_as(C.c_void_p), C.c_uint64(words.size),
+                                         out2.ctypes.data_as(C.c_void_p), C.byref(used))
+        assert rc == 0
+        assert (out1 == out2).all(), (case, n_reads, probs, out1, out2)
+        assert int(out1.sum()) == n_reads
+
+
 # ---- PacBio arithmetic (csrc/jk_math2.h, jk_nmath.h) ---------------------------------------------
 
 def eval2(fn, what, xs, per=1):
