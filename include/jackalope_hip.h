@@ -224,6 +224,9 @@ int jk_session_write_shard(const jk_session* s, const uint64_t file_offset[2]);
 int jk_session_timing(const jk_session* s, double ms[3]);
 /* Number of generator launches (batches of lanes) one generate() makes. */
 uint32_t jk_session_batches(const jk_session* s);
+/* PacBio: how often the last generate() re-planned its buffers and ran again (a lane's pool or the FASTQ image, both
+ * sized from the read-length model, turned out too small; the kernels never write past either). */
+uint32_t jk_session_retries(const jk_session* s);
 /* Number of sub-seed words consumed while opening the session. */
 uint64_t jk_session_seed_words_used(const jk_session* s);
 /* Positions [begin, end) in the seed-word stream of the add_n_reads words of this shard's lanes (after the

@@ -111,7 +111,7 @@ EXPORTS = [
     "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_pacbio_ref_open", "jk_pacbio_hap_open", "jk_session_generate", "jk_session_sizes",
     "jk_session_device_ptr", "jk_session_fetch", "jk_session_fetch_range", "jk_session_write", "jk_session_write_shard",
     "jk_session_shard_seed_words", "jk_session_timing",
-    "jk_session_seed_words_used", "jk_session_batches", "jk_session_lane_bytes", "jk_session_close",
+    "jk_session_seed_words_used", "jk_session_retries", "jk_session_batches", "jk_session_lane_bytes", "jk_session_close",
     "jk_split_int", "jk_reads_per_group", "jk_plan_lane_quotas", "jk_alias_build", "jk_hap_chrom_full",
     "jk_host_eval", "jk_dev_eval", "jk_eval_set_gamma", "jk_x87_one_minus",
     "jk_hap_builder_new", "jk_hap_builder_from", "jk_add_substitution", "jk_add_insertion", "jk_add_deletion",
@@ -143,6 +143,8 @@ def lib():
     L.jk_version.restype = C.c_char_p
     L.jk_session_seed_words_used.restype = C.c_uint64
     L.jk_session_seed_words_used.argtypes = [C.c_void_p]
+    L.jk_session_retries.restype = C.c_uint32
+    L.jk_session_retries.argtypes = [C.c_void_p]
     L.jk_session_batches.restype = C.c_uint32
     L.jk_session_batches.argtypes = [C.c_void_p]
     L.jk_illumina_ref.argtypes = [C.POINTER(RefGenomeView), C.POINTER(IlluminaArgs)]

@@ -123,6 +123,9 @@ static void launch_generate(jk_session& s) {
     if (err & JK_KERR_PB_MATH) throw Error(JK_ERR_UNSUPPORTED, "a PacBio parameter led to an exp/pow argument outside the range implemented on the GPU");
     if (err & JK_KERR_PB_TOO_LONG) throw Error(JK_ERR_UNSUPPORTED, "a read was longer than the GPU path's cap (9 sigma of the log-normal, or it needed > 2x its length in reference positions)");
     if (err & JK_KERR_PB_SPACE) throw Error(JK_ERR_UNSUPPORTED, "a read position lies outside the reference's read buffer (undefined there: a read as long as its chromosome or a clipped duplicate with no earlier, longer read on its thread) or needs more chromosome than there is");
+    // PacBio images are sized for the expected read length (the pools' worst case would not fit): a length model whose
+    // realised mean is above that (e.g. min_read_length cutting off most of the log-normal) gets a larger image
+    if ((err & JK_KERR_IMAGE_FULL) && s.pacbio && s.replan && !std::getenv("JK_PB_NO_IMAGE_RETRY")) throw Error(JK_ERR_RETRY_IMAGE, "image full");
     if (err & JK_KERR_IMAGE_FULL) throw Error(JK_ERR_DEVICE, "the FASTQ image of this run does not fit in device memory next to its pools: use more GPUs (lane shards) or fewer reads per call");
     if ((err & JK_KERR_POOL_OVERFLOW) && s.pacbio) throw Error(JK_ERR_RETRY, "pool overflow");
     if (err & JK_KERR_POOL_OVERFLOW) throw Error(JK_ERR_DEVICE, "internal error: a lane overflowed its pool region");

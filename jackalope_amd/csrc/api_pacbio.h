@@ -136,7 +136,7 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     // the image: expected bytes (mean read length) + 12.5 % + 64 MB, not the pools' worst case (every read of maximal length)
     uint64_t n_reads_shard = 0;
     for (uint64_t l = 0; l < s.n_shard; l++) n_reads_shard += lane_reads[l];
-    const uint64_t image_hint = n_reads_shard * (max_hdr + n_digits(max_chrom) + 3 + 2 * (uint64_t)std::ceil(M.len_mean) + 8);
+    const uint64_t image_hint = (uint64_t)((double)(n_reads_shard * (max_hdr + n_digits(max_chrom) + 3 + 2 * (uint64_t)std::ceil(M.len_mean) + 8)) * s.image_scale);
     const uint32_t max_lanes = plan_pools_common(s, max_batch_bytes ? max_batch_bytes : (48ULL << 30), 1ULL << 18,
                                                  lane_cap, lane_reads, lane_seeds, quotas, image_hint);
     s.ev_words = (uint32_t)((2 * M.len_cap + 64 + 31) / 32);

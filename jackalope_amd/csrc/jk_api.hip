@@ -88,14 +88,18 @@ int jk_illumina_hap_open(const jk_hap_set* haps, const jk_illumina_args* args, j
 }
 
 static void generate_with_retry(jk_session& s) {
+    s.retries = 0;
     for (int attempt = 0;; attempt++) {
         try { launch_generate(s); return; }
         catch (const Error& e) {
-            if (e.code != JK_ERR_RETRY || attempt >= 6 || !s.replan) {
+            const bool again = (e.code == JK_ERR_RETRY || e.code == JK_ERR_RETRY_IMAGE) && attempt < 6 && s.replan;
+            if (!again) {
                 if (e.code == JK_ERR_RETRY) throw Error(JK_ERR_DEVICE, "PacBio pools overflowed even after growing them");
+                if (e.code == JK_ERR_RETRY_IMAGE) throw Error(JK_ERR_DEVICE, "the PacBio FASTQ image overflowed even after growing it");
                 throw;
             }
-            s.pool_scale *= 2;
+            if (e.code == JK_ERR_RETRY) s.pool_scale *= 2; else s.image_scale *= 2;
+            s.retries++;
             s.replan();
         }
     }
@@ -232,6 +236,7 @@ int jk_session_timing(const jk_session* s, double ms[3]) {
 }
 
 uint64_t jk_session_seed_words_used(const jk_session* s) { return s ? s->seed_words_used : 0; }
+uint32_t jk_session_retries(const jk_session* s) { return s ? s->retries : 0; }
 uint32_t jk_session_batches(const jk_session* s) { return s ? (uint32_t)s->batches.size() : 0; }
 
 int jk_session_lane_bytes(const jk_session* s, uint32_t end, uint64_t* out, uint64_t n) {

@@ -41,6 +41,7 @@ struct DevBuf {
 };
 
 constexpr int JK_ERR_RETRY = 1000;   // internal: PacBio pools were too small, regenerate with larger ones
+constexpr int JK_ERR_RETRY_IMAGE = 1001;   // internal: the PacBio image (sized for the expected read length) was too small
 
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 static inline uint32_t n_digits(uint64_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; d++; } return d; }

@@ -38,6 +38,8 @@ struct jk_session {
     uint32_t ev_words = 0;
     uint64_t nuc_base = 0;     // offset of the haplotypes' nucleotide blob inside d_seq
     double pool_scale = 1.25;  // PacBio: pool capacity relative to the expected bytes (grown on overflow)
+    double image_scale = 1.0;  // PacBio: image capacity relative to the expected bytes (grown when the compaction ran out of image)
+    uint32_t retries = 0;      // re-plans of the last generate() (pool or image too small)
     std::function<void()> replan;   // PacBio: re-plan pools after pool_scale changed
     DevBuf d_bucket_off, d_bucket, d_cell_off, d_new_pos, d_ref_shift, d_nuc_len, d_nuc_off, d_cell_size, d_bc_blob, d_bc_len;
     // lanes of this shard

@@ -140,6 +140,9 @@ class IlluminaSession:
     def seed_words_used(self):
         return int(_abi.lib().jk_session_seed_words_used(self._h))
 
+    def retries(self):
+        return int(_abi.lib().jk_session_retries(self._h))
+
     def lane_bytes(self, end, n_lanes):
         out = np.empty(n_lanes, dtype=np.uint64)
         _abi.check(_abi.lib().jk_session_lane_bytes(self._h, end, out.ctypes.data, n_lanes))
@@ -166,7 +169,8 @@ class IlluminaSession:
 def make_args(out_prefix, n_reads, paired, matepair, prof1, prof2, ins_prob1, del_prob1, ins_prob2, del_prob2,
               frag_len_shape, frag_len_scale, frag_len_min, frag_len_max, barcodes, prob_dup, n_threads,
               read_pool_size, words, compress=0, comp_method="bgzip", sep_files=False, haplotype_probs=None,
-              lane_begin=0, lane_end=0, device=0, max_batch_bytes=0, seed_fn=None, abort_flag=None):
+              lane_begin=0, lane_end=0, device=0, max_batch_bytes=0, seed_fn=None, abort_flag=None, seed_offset_words=None,
+              devices=None):
     """Assemble jk_illumina_args; returns (struct, keep-alive list)."""
     a = _abi.IlluminaArgs()
     keep = []
@@ -222,6 +226,12 @@ def make_args(out_prefix, n_reads, paired, matepair, prof1, prof2, ins_prob1, de
     a.lane_begin, a.lane_end = int(lane_begin), int(lane_end)
     a.device = int(device)
     a.max_batch_bytes = int(max_batch_bytes)
+    if seed_offset_words is not None:
+        a.seed_offset_given, a.seed_offset_words = 1, int(seed_offset_words)
+    if devices is not None:
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        keep.append(dv)
+        a.devices, a.n_devices = dv.ctypes.data_as(C.POINTER(C.c_int32)), dv.size
     return a, keep
 
 
@@ -231,7 +241,7 @@ def illumina(obj, out_prefix, n_reads, read_length, paired, frag_mean=400, frag_
              barcodes=None, prob_dup=0.02, sep_files=False, compress=False, comp_method="bgzip", n_threads=1,
              read_pool_size=1000, show_progress=False, overwrite=False,
              seed=None, seed_words=None, device=0, lane_begin=0, lane_end=0, max_batch_bytes=0, _session=False,
-             seed_fn=None, abort_flag=None):
+             seed_fn=None, abort_flag=None, seed_offset_words=None, devices=None):
     """Create and write Illumina reads (R/hts_illumina.R:593-732).
 
     With ``_session=True`` nothing is written: the opened `IlluminaSession` is returned instead
@@ -286,7 +296,7 @@ def illumina(obj, out_prefix, n_reads, read_length, paired, frag_mean=400, frag_
     args, keep = make_args(out_prefix, n_reads, paired, matepair, prof1, prof2, ins_prob1, del_prob1, ins_prob2,
                            del_prob2, frag_len_shape, frag_len_scale, frag_len_min, frag_len_max, barcodes, prob_dup,
                            n_threads, read_pool_size, seed_words, compress, comp_method, sep_files, haplotype_probs,
-                           lane_begin, lane_end, device, max_batch_bytes, seed_fn, abort_flag)
+                           lane_begin, lane_end, device, max_batch_bytes, seed_fn, abort_flag, seed_offset_words, devices)
     L = _abi.lib()
     if is_ref:
         view, keep2 = obj._view()

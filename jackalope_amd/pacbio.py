@@ -62,7 +62,8 @@ def pacbio(obj, out_prefix, n_reads,
            lognorm_read_length=(0.200110276521, -10075.4363813, 17922.611306), custom_read_lengths=None,
            prob_dup=0.0, haplotype_probs=None, sep_files=False, compress=False, comp_method="bgzip", n_threads=1,
            read_pool_size=100, show_progress=False, overwrite=False,
-           seed=None, seed_words=None, device=0, lane_begin=0, lane_end=0, max_batch_bytes=0, _session=False):
+           seed=None, seed_words=None, device=0, lane_begin=0, lane_end=0, max_batch_bytes=0, _session=False,
+           seed_offset_words=None, devices=None):
     """Create and write PacBio reads (R/hts_pacbio.R:232-348).  ``_session=True`` returns the opened
     session (FASTQ stays in HBM) instead of writing ``<out_prefix>_R1.fq``."""
     check_pacbio_args(obj, n_reads, haplotype_probs, sep_files, compress, comp_method, n_threads, read_pool_size,
@@ -119,6 +120,12 @@ def pacbio(obj, out_prefix, n_reads,
     a.seeds.words = words.ctypes.data_as(C.POINTER(C.c_uint32))
     a.seeds.n_words = words.size
     a.lane_begin, a.lane_end, a.device, a.max_batch_bytes = int(lane_begin), int(lane_end), int(device), int(max_batch_bytes)
+    if seed_offset_words is not None:
+        a.seed_offset_given, a.seed_offset_words = 1, int(seed_offset_words)
+    if devices is not None:
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        keep.append(dv)
+        a.devices, a.n_devices = dv.ctypes.data_as(C.POINTER(C.c_int32)), dv.size
     L = _abi.lib()
     view, keep2 = obj._view()
     if _session:

@@ -539,6 +539,24 @@ struct HapChrom {
 
 struct HapGenome { std::string name; std::vector<HapChrom> chroms; };
 
+// Test-speed option (orc_set_chrom_cache): the reference materialises a haplotype chromosome with get_chrom_full()
+// every time a thread's cursor enters a (haplotype, chromosome) cell.  The string is a pure function of the cell,
+// so for genome-scale windows (24 x 125 Mbp x 4-8 haplotypes per thread) the cells are materialised once, in
+// parallel, and the threads read the shared copies.  Same bytes, fewer repetitions.
+struct ChromCache {
+    u64 n_chroms = 0;
+    std::vector<std::string> seq;                 // [hap * n_chroms + chr]
+    void build(const std::vector<HapGenome>& haps) {
+        n_chroms = haps.empty() ? 0 : haps[0].chroms.size();
+        seq.assign(haps.size() * n_chroms, std::string());
+        const long n = (long)seq.size();
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long k = 0; k < n; k++) seq[k] = haps[k / n_chroms].chroms[k % n_chroms].get_chrom_full();
+    }
+};
+static bool g_use_chrom_cache = false;
+static const ChromCache* g_chrom_cache = nullptr;   // set for the duration of one orc_*_hap call
+
 // IlluminaHaplotypes (src/hts_illumina.h:509-675, src/hts_illumina.cpp:495-558)
 struct IlluminaHaplotypes {
     const std::vector<HapGenome>* haps;
@@ -549,6 +567,8 @@ struct IlluminaHaplotypes {
     std::vector<double> hap_probs;
     u64 hap, chr;
     std::string hap_chrom_seq;
+    const std::string* cached_seq = nullptr;     // ChromCache entry standing in for hap_chrom_seq
+    const std::string& cur_seq() const { return cached_seq ? *cached_seq : hap_chrom_seq; }
 
     IlluminaHaplotypes(const std::vector<HapGenome>& hs, const std::vector<double>& probs,
                        const IlluminaParams& p, std::vector<std::string> barcodes)
@@ -569,7 +589,7 @@ struct IlluminaHaplotypes {
     // The copy made per thread must re-point each read maker at this object's genome views.
     IlluminaHaplotypes(const IlluminaHaplotypes& o)
         : haps(o.haps), genomes(o.genomes), n_reads_vc(o.n_reads_vc), read_makers(o.read_makers),
-          paired(o.paired), hap_probs(o.hap_probs), hap(o.hap), chr(o.chr), hap_chrom_seq(o.hap_chrom_seq) {
+          paired(o.paired), hap_probs(o.hap_probs), hap(o.hap), chr(o.chr), hap_chrom_seq(o.hap_chrom_seq), cached_seq(o.cached_seq) {
         for (u64 i = 0; i < read_makers.size(); i++) read_makers[i].genome = &genomes[i];
     }
 
@@ -590,7 +610,7 @@ struct IlluminaHaplotypes {
     // src/hts_illumina.cpp:495-536
     void one_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
         if (hap == haps->size()) { finished = true; return; }
-        if (n_reads_vc[hap][chr] == 0 || hap_chrom_seq.empty()) {
+        if (n_reads_vc[hap][chr] == 0 || cur_seq().empty()) {
             u64 new_hap = hap, new_chr = chr;
             for (; new_hap < n_reads_vc.size(); new_hap++) {
                 while (n_reads_vc[new_hap][new_chr] == 0) {
@@ -602,16 +622,17 @@ struct IlluminaHaplotypes {
             }
             hap = new_hap; chr = new_chr;
             if (hap == haps->size()) { finished = true; return; }
-            hap_chrom_seq = (*haps)[hap].chroms[chr].get_chrom_full();
+            if (g_chrom_cache) cached_seq = &g_chrom_cache->seq[hap * g_chrom_cache->n_chroms + chr];
+            else hap_chrom_seq = (*haps)[hap].chroms[chr].get_chrom_full();
         }
-        read_makers[hap].one_read_str(hap_chrom_seq, chr, pools, eng);
+        read_makers[hap].one_read_str(cur_seq(), chr, pools, eng);
         n_reads_vc[hap][chr]--;
         if (paired && n_reads_vc[hap][chr] > 0) n_reads_vc[hap][chr]--;
     }
     // src/hts_illumina.cpp:542-558
     void re_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
         if (hap == haps->size()) { finished = true; return; }
-        read_makers[hap].re_read_str(hap_chrom_seq, chr, pools, eng);
+        read_makers[hap].re_read_str(cur_seq(), chr, pools, eng);
         if (n_reads_vc[hap][chr] > 0) n_reads_vc[hap][chr]--;
         if (paired && n_reads_vc[hap][chr] > 0) n_reads_vc[hap][chr]--;
     }
@@ -625,6 +646,7 @@ struct IlluminaHaplotypes {
 struct RunOpts {
     u64 thread_begin = 0, thread_end = 0;   // only these threads generate (0,0 = all); seeds/quotas are
                                             // still derived for every thread, so the kept ones are unchanged
+    std::vector<std::pair<u64, u64>> windows;   // several such windows in one run (orc_set_windows); output in window order
     bool discard = false;                   // count bytes only (null sink, for timing)
     std::vector<std::vector<u64>> thread_bytes;   // out: [end][thread]
 };
@@ -640,29 +662,41 @@ static void run_threads(const Filler& base, u64 n_reads, double prob_dup, u64 re
     for (u64 t = 0; t < n_threads; t++) tseeds[t] = seeds.take8();
     // Threads outside the generation window only need their seed words consumed: run add_n_reads on one
     // scratch copy for them instead of keeping a filler each.
-    const u64 tb = opts.thread_begin, te = opts.thread_end ? opts.thread_end : n_threads;
+    std::vector<std::pair<u64, u64>> wins = opts.windows;
+    if (wins.empty()) wins.push_back({opts.thread_begin, opts.thread_end ? opts.thread_end : n_threads});
+    std::vector<u64> gen;                    // the threads that generate, in output order
+    for (auto& w : wins) {
+        if (w.second > n_threads) w.second = n_threads;
+        if (!gen.empty() && w.first < gen.back() + 1) throw std::runtime_error("thread windows must be increasing and disjoint");
+        for (u64 t = w.first; t < w.second; t++) gen.push_back(t);
+    }
     std::vector<Filler> fillers;
-    fillers.reserve(te > tb ? te - tb : 0);
+    fillers.reserve(gen.size());
     Filler scratch(base);
-    for (u64 t = 0; t < n_threads; t++) {
-        if (t >= tb && t < te) {
-            fillers.push_back(base);
-            fillers.back().add_n_reads(reads_per_thread[t], seeds);
-        } else {
-            scratch.reset_quota();
-            scratch.add_n_reads(reads_per_thread[t], seeds);
+    {
+        size_t gi = 0;
+        for (u64 t = 0; t < n_threads; t++) {
+            if (gi < gen.size() && gen[gi] == t) {
+                fillers.push_back(base);
+                fillers.back().add_n_reads(reads_per_thread[t], seeds);
+                gi++;
+            } else {
+                scratch.reset_quota();
+                scratch.add_n_reads(reads_per_thread[t], seeds);
+            }
         }
     }
     files.assign(n_read_ends, std::vector<char>());
     // Threads are independent (own filler copy, own engine), so they may run concurrently; each
     // keeps its own output and the pieces are concatenated in thread order afterwards.
-    std::vector<std::vector<std::vector<char>>> outs(te > tb ? te - tb : 0, std::vector<std::vector<char>>(n_read_ends));
+    std::vector<std::vector<std::vector<char>>> outs(gen.size(), std::vector<std::vector<char>>(n_read_ends));
     opts.thread_bytes.assign(n_read_ends, std::vector<u64>(n_threads, 0));
 #pragma omp parallel for schedule(dynamic, 1)
-    for (u64 t = tb; t < te; t++) {
-        std::vector<std::vector<char>>& files = outs[t - tb];
+    for (u64 gk = 0; gk < gen.size(); gk++) {
+        const u64 t = gen[gk];
+        std::vector<std::vector<char>>& files = outs[gk];
         Pcg64 eng = seeded_pcg(tseeds[t]);
-        Filler& filler = fillers[t - tb];
+        Filler& filler = fillers[gk];
         const u64 n = reads_per_thread[t];
         u64 reads_made = 0, reads_in_pool = 0;
         std::vector<std::vector<char>> pools(n_read_ends);
@@ -1185,6 +1219,8 @@ struct PacBioHaplotypes {
     std::vector<double> hap_probs;
     u64 hap, chr;
     std::string hap_chrom_seq;
+    const std::string* cached_seq = nullptr;     // ChromCache entry standing in for hap_chrom_seq
+    const std::string& cur_seq() const { return cached_seq ? *cached_seq : hap_chrom_seq; }
     PacBioHaplotypes(const std::vector<HapGenome>& hs, const std::vector<double>& probs, const PacBioParams& p)
         : haps(&hs), hap_probs(probs), hap(0), chr(0) {
         genomes.resize(hs.size());
@@ -1201,7 +1237,7 @@ struct PacBioHaplotypes {
     }
     PacBioHaplotypes(const PacBioHaplotypes& o)
         : haps(o.haps), genomes(o.genomes), n_reads_vc(o.n_reads_vc), read_makers(o.read_makers), hap_probs(o.hap_probs),
-          hap(o.hap), chr(o.chr), hap_chrom_seq(o.hap_chrom_seq) {
+          hap(o.hap), chr(o.chr), hap_chrom_seq(o.hap_chrom_seq), cached_seq(o.cached_seq) {
         for (u64 i = 0; i < read_makers.size(); i++) read_makers[i].genome = &genomes[i];
     }
     void reset_quota() { n_reads_vc.clear(); for (auto& rm : read_makers) rm.reset_quota(); }
@@ -1217,7 +1253,7 @@ struct PacBioHaplotypes {
     }
     void one_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
         if (hap == haps->size()) { finished = true; return; }
-        if (n_reads_vc[hap][chr] == 0 || hap_chrom_seq.empty()) {
+        if (n_reads_vc[hap][chr] == 0 || cur_seq().empty()) {
             u64 new_hap = hap, new_chr = chr;
             for (; new_hap < n_reads_vc.size(); new_hap++) {
                 while (n_reads_vc[new_hap][new_chr] == 0) {
@@ -1229,14 +1265,15 @@ struct PacBioHaplotypes {
             }
             hap = new_hap; chr = new_chr;
             if (hap == haps->size()) { finished = true; return; }
-            hap_chrom_seq = (*haps)[hap].chroms[chr].get_chrom_full();
+            if (g_chrom_cache) cached_seq = &g_chrom_cache->seq[hap * g_chrom_cache->n_chroms + chr];
+            else hap_chrom_seq = (*haps)[hap].chroms[chr].get_chrom_full();
         }
-        read_makers[hap].one_read_str(hap_chrom_seq, chr, pools, eng);
+        read_makers[hap].one_read_str(cur_seq(), chr, pools, eng);
         n_reads_vc[hap][chr]--;
     }
     void re_read(std::vector<std::vector<char>>& pools, bool& finished, Pcg64& eng) {
         if (hap == haps->size()) { finished = true; return; }
-        read_makers[hap].re_read_str(hap_chrom_seq, chr, pools, eng);
+        read_makers[hap].re_read_str(cur_seq(), chr, pools, eng);
         if (n_reads_vc[hap][chr] > 0) n_reads_vc[hap][chr]--;
     }
 };
@@ -1251,6 +1288,15 @@ extern "C" {
 
 const char* orc_last_error(void) { return g_err.c_str(); }
 void orc_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+// Options for the following orc_illumina_* / orc_pacbio_* calls (genome-scale tests):
+// windows = n pairs {begin, end} of thread indices, increasing and disjoint: only those threads generate (n = 0: back
+// to the args' thread_begin/thread_end); chrom cache: see ChromCache.
+static std::vector<std::pair<u64, u64>> g_windows;
+void orc_set_windows(const uint64_t* bounds, uint64_t n) {
+    g_windows.clear();
+    for (uint64_t i = 0; i < n; i++) g_windows.push_back({bounds[2 * i], bounds[2 * i + 1]});
+}
+void orc_set_chrom_cache(int on) { g_use_chrom_cache = on != 0; }
 int orc_max_threads(void) { return omp_get_max_threads(); }
 void orc_free(void* p) { std::free(p); }
 
@@ -1397,7 +1443,7 @@ int orc_illumina_ref(uint64_t n_chroms, const char* const* chrom_names, const ch
         IlluminaOneGenome base(g, p, barcode ? barcode : "");
         SeedSource seeds{a->seed_words, a->n_seed_words, 0};
         std::vector<std::vector<char>> files;
-        RunOpts opts; opts.thread_begin = a->thread_begin; opts.thread_end = a->thread_end; opts.discard = a->discard != 0;
+        RunOpts opts; opts.thread_begin = a->thread_begin; opts.thread_end = a->thread_end; opts.discard = a->discard != 0; opts.windows = g_windows;
         run_threads(base, a->n_reads, a->prob_dup, a->read_pool_size, a->paired ? 2 : 1, a->n_threads, seeds, files, opts);
         export_thread_bytes(a, opts);
         give(files[0], out1, len1);
@@ -1461,9 +1507,12 @@ int orc_illumina_hap(const orc_hap_set* hs, const double* hap_probs, const orc_i
         std::vector<std::string> bcs;
         for (uint64_t i = 0; i < n_barcodes; i++) bcs.push_back(barcodes[i]);
         IlluminaHaplotypes base(haps, std::vector<double>(hap_probs, hap_probs + hs->n_haps), p, bcs);
+        ChromCache cache;
+        struct CacheScope { ~CacheScope() { g_chrom_cache = nullptr; } } scope;
+        if (g_use_chrom_cache) { cache.build(haps); g_chrom_cache = &cache; }
         SeedSource seeds{a->seed_words, a->n_seed_words, 0};
         std::vector<std::vector<char>> files;
-        RunOpts opts; opts.thread_begin = a->thread_begin; opts.thread_end = a->thread_end; opts.discard = a->discard != 0;
+        RunOpts opts; opts.thread_begin = a->thread_begin; opts.thread_end = a->thread_end; opts.discard = a->discard != 0; opts.windows = g_windows;
         run_threads(base, a->n_reads, a->prob_dup, a->read_pool_size, a->paired ? 2 : 1, a->n_threads, seeds, files, opts);
         export_thread_bytes(a, opts);
         give(files[0], out1, len1);
@@ -1508,7 +1557,7 @@ template <typename Filler>
 static void run_pacbio(const Filler& base, const orc_pacbio_args* a, char** out, uint64_t* len, uint64_t* used) {
     SeedSource seeds{a->seed_words, a->n_seed_words, 0};
     std::vector<std::vector<char>> files;
-    RunOpts opts; opts.thread_begin = a->thread_begin; opts.thread_end = a->thread_end; opts.discard = a->discard != 0;
+    RunOpts opts; opts.thread_begin = a->thread_begin; opts.thread_end = a->thread_end; opts.discard = a->discard != 0; opts.windows = g_windows;
     run_threads(base, a->n_reads, a->prob_dup, a->read_pool_size, 1, a->n_threads, seeds, files, opts);
     if (a->thread_bytes) for (u64 t = 0; t < a->n_threads; t++) a->thread_bytes[t] = opts.thread_bytes[0][t];
     give(files[0], out, len);
@@ -1542,6 +1591,9 @@ int orc_pacbio_hap(const orc_hap_set* hs, const double* hap_probs, const orc_pac
         std::vector<std::string> refs; std::vector<HapGenome> haps;
         build_haps(hs, refs, haps);
         PacBioHaplotypes base(haps, std::vector<double>(hap_probs, hap_probs + hs->n_haps), to_pb_params(a));
+        ChromCache cache;
+        struct CacheScope { ~CacheScope() { g_chrom_cache = nullptr; } } scope;
+        if (g_use_chrom_cache) { cache.build(haps); g_chrom_cache = &cache; }
         run_pacbio(base, a, out, len, seed_words_used);
         return 0;
     } catch (std::exception& e) { g_err = e.what(); return 1; }

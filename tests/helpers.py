@@ -115,3 +115,45 @@ def write_fai(fn, names, chroms, text_width=80, newline_len=1):
             n_lines = (len(c) + text_width - 1) // text_width
             at += len(c) + n_lines * newline_len
     return fn
+
+
+class DeviceImage:
+    """A session's FASTQ image of one read end as a torch uint8 tensor over the session's own device memory (no copy):
+    whole-image properties of 100-200 GB images are computed where they lie."""
+
+    def __init__(self, session, end):
+        import torch
+        sizes, _ = session.sizes()
+        self.n = int(sizes[end])
+        self.__cuda_array_interface__ = {"shape": (self.n,), "typestr": "|u1", "data": (session.device_ptr(end), False), "version": 2}
+        self.t = torch.as_tensor(self, device="cuda") if self.n else torch.zeros(0, dtype=torch.uint8, device="cuda")
+
+    def count(self, byte, lo=0, hi=None, chunk=1 << 30):
+        hi = self.n if hi is None else hi
+        total = 0
+        for a in range(lo, hi, chunk):
+            total += int((self.t[a:min(a + chunk, hi)] == byte).sum().item())
+        return total
+
+    def byte_sum(self, lo=0, hi=None, chunk=1 << 30):
+        import torch
+        hi = self.n if hi is None else hi
+        total = 0
+        for a in range(lo, hi, chunk):
+            total += int(self.t[a:min(a + chunk, hi)].sum(dtype=torch.int64).item())
+        return total
+
+    def weighted_sum(self, lo, hi, chunk=1 << 28):
+        """sum over the range of byte * (1 + (position in range) mod 65521): moves when bytes are permuted."""
+        import torch
+        total = 0
+        for a in range(lo, hi, chunk):
+            b = min(a + chunk, hi)
+            w = (torch.arange(a - lo, b - lo, device="cuda", dtype=torch.int64) % 65521) + 1
+            total += int((self.t[a:b].to(torch.int64) * w).sum().item())
+        return total
+
+    def at(self, offsets):
+        import torch
+        idx = torch.as_tensor(np.asarray(offsets, dtype=np.int64), device="cuda")
+        return self.t[idx].cpu().numpy()

@@ -160,9 +160,32 @@ def illumina_ref(genome, *, paired, matepair=False, n_reads, prob_dup, n_threads
     return r1, r2, used.value
 
 
+def set_windows(windows):
+    """Only the threads of these [begin, end) windows generate in the following oracle runs (increasing, disjoint);
+    the output is their concatenation in order.  None/[] = back to thread_begin/thread_end."""
+    w = np.ascontiguousarray(windows if windows else [], dtype=np.uint64).reshape(-1)
+    lib().orc_set_windows(w.ctypes.data_as(C.c_void_p), C.c_uint64(w.size // 2))
+
+
+def set_chrom_cache(on):
+    """Materialise every haplotype chromosome once per oracle call (in parallel) instead of once per thread and cell."""
+    lib().orc_set_chrom_cache(C.c_int(int(bool(on))))
+
+
 def _hap_view(hs):
-    """OrcHapSet struct + keep-alive list from a jackalope_amd.genome.HapSet."""
+    """OrcHapSet struct + keep-alive list from a jackalope_amd.genome.HapSet (or FlatHapSet: arrays passed as they are)."""
     nh, nc = hs.n_haps(), hs.ref.n_chroms()
+    if not hasattr(hs, "cells"):
+        v = OrcHapSet()
+        v.n_haps, v.n_chroms = nh, nc
+        hn = (C.c_char_p * nh)(*[x.encode() for x in hs.names])
+        cn = (C.c_char_p * nc)(*[x.encode() for x in hs.ref.names])
+        rs = (C.c_void_p * nc)(*[s.ctypes.data for s in hs.ref.seqs])
+        rl = (C.c_uint64 * nc)(*hs.ref.sizes())
+        v.hap_names, v.chrom_names, v.ref_seqs, v.ref_lens = hn, cn, rs, rl
+        v.chrom_size, v.n_mut = hs.chrom_size.ctypes.data, hs.n_mut.ctypes.data
+        v.old_pos, v.new_pos, v.nuc_off, v.nuc_blob = hs.old_pos.ctypes.data, hs.new_pos.ctypes.data, hs.nuc_off.ctypes.data, hs.blob.ctypes.data
+        return v, [hn, cn, rs, rl, hs]
     chrom_size = np.zeros(nh * nc, dtype=np.uint64)
     n_mut = np.zeros(nh * nc, dtype=np.uint64)
     old_pos, new_pos, nuc_off, blob = [], [], [0], []
