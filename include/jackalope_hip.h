@@ -145,6 +145,12 @@ typedef struct jk_illumina_args {
      * src/hts.h:357-417.) */
     const int32_t* devices;
     uint32_t n_devices;
+    /* Session API: 1 = this session streams (jk_session_run): every generator launch's FASTQ goes to the sink as it
+     * completes -- device BGZF when asked for, pinned double-buffered copy to the host, file writes on writer threads,
+     * all overlapped with the next launch -- and no image stays in device memory, so a run is not limited by it
+     * (the reference flushes pool by pool, src/hts.h:401-412).  jk_session_generate / _fetch / _write are then not
+     * available.  The one-shot entry points always stream. */
+    int32_t stream_output;
 } jk_illumina_args;
 
 /* Arguments of pacbio_ref_cpp / pacbio_hap_cpp, same names and meaning (src/hts_pacbio.cpp:579-602, :646-671). */
@@ -179,6 +185,7 @@ typedef struct jk_pacbio_args {
     uint64_t seed_offset_words;
     const int32_t* devices;           /* as in jk_illumina_args (jk_pacbio_ref / jk_pacbio_hap) */
     uint32_t n_devices;
+    int32_t stream_output;            /* as in jk_illumina_args */
 } jk_pacbio_args;
 
 const char* jk_last_error(void);
@@ -189,6 +196,26 @@ int jk_illumina_ref(const jk_ref_genome* genome, const jk_illumina_args* args);
 int jk_illumina_hap(const jk_hap_set* haps, const jk_illumina_args* args);
 int jk_pacbio_ref(const jk_ref_genome* genome, const jk_pacbio_args* args);
 int jk_pacbio_hap(const jk_hap_set* haps, const jk_pacbio_args* args);
+
+/* Jobs: a one-shot call in two steps per output file set, for hosts whose RNG and interrupt handling live on one
+ * thread (R).  A file set is the pair <prefix>_R1/_R2 -- one per call, or one per haplotype with sep_files
+ * (write_reads_cpp_sep_files_, src/hts.h:512-552).  jk_job_plan_next does, on the calling thread, what the reference
+ * does before its parallel region for the next file set -- it is the only step that reads seed words (mt_seeds, then
+ * the add_n_reads of every thread, src/hts.h:339,349-353) -- and jk_job_run then generates and writes that file set on
+ * args.devices from any thread, while another thread may poll jk_job_progress (the reference's progress bar,
+ * src/hts.h:414) and raise *args.abort_flag (Progress::check_abort, src/hts.h:396-399).  The genome / haplotype views
+ * and everything the args point to are borrowed until jk_job_free.  jk_illumina_ref & co. are exactly this loop. */
+typedef struct jk_job jk_job;
+int jk_illumina_ref_job(const jk_ref_genome* genome, const jk_illumina_args* args, jk_job** out);
+int jk_illumina_hap_job(const jk_hap_set* haps, const jk_illumina_args* args, jk_job** out);
+int jk_pacbio_ref_job(const jk_ref_genome* genome, const jk_pacbio_args* args, jk_job** out);
+int jk_pacbio_hap_job(const jk_hap_set* haps, const jk_pacbio_args* args, jk_job** out);
+uint32_t jk_job_n_files(const jk_job* j);
+int jk_job_plan_next(jk_job* j);
+int jk_job_run(jk_job* j);
+int jk_job_progress(const jk_job* j, uint64_t* reads_done, uint64_t* reads_total);
+uint64_t jk_job_seed_words_used(const jk_job* j);
+void jk_job_free(jk_job* j);
 
 /* Session API (what the one-shot calls are made of; used by tests and bench.py so that the
  * generated FASTQ can stay resident in HBM). */
@@ -201,6 +228,13 @@ int jk_pacbio_hap_open(const jk_hap_set* haps, const jk_pacbio_args* args, jk_se
 /* Run every batch of this session's lanes: generator kernel, per-lane byte-count scan, pool
  * compaction into the lane-major FASTQ images.  May be called repeatedly (same output each time). */
 int jk_session_generate(jk_session* s);
+/* Streaming sessions (args.stream_output): run every batch and write <out_prefix>_R<e+1>.fq[.gz] while generating.
+ * out_prefix "" (or NULL) = null sink: the FASTQ (or its BGZF form when compress > 0) is brought to host memory and
+ * dropped, which is what bench.py times as the D2H-inclusive rate.  Blocks until the files are closed; another thread
+ * may poll jk_session_progress meanwhile and raise *args.abort_flag to stop it (JK_ERR_ABORTED). */
+int jk_session_run(jk_session* s);
+/* Reads whose FASTQ has left the device so far / reads planned for this session's lanes.  Thread-safe. */
+int jk_session_progress(const jk_session* s, uint64_t* reads_done, uint64_t* reads_total);
 /* bytes[e] = FASTQ bytes of read end e (e < n_ends); reads = reads made (all ends). */
 int jk_session_sizes(const jk_session* s, uint64_t bytes[2], uint64_t* reads, uint32_t* n_ends);
 /* Device pointer of the FASTQ image of read end e (valid until the next generate/close). */

@@ -81,7 +81,8 @@ class IlluminaArgs(C.Structure):
                 ("device", C.c_int32),
                 ("max_batch_bytes", C.c_uint64),
                 ("seed_offset_given", C.c_int32), ("seed_offset_words", C.c_uint64),
-                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32)]
+                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32),
+                ("stream_output", C.c_int32)]
 
 
 class PacbioArgs(C.Structure):
@@ -102,13 +103,16 @@ class PacbioArgs(C.Structure):
                 ("device", C.c_int32),
                 ("max_batch_bytes", C.c_uint64),
                 ("seed_offset_given", C.c_int32), ("seed_offset_words", C.c_uint64),
-                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32)]
+                ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32),
+                ("stream_output", C.c_int32)]
 
 
 # every symbol include/jackalope_hip.h declares
 EXPORTS = [
     "jk_last_error", "jk_version", "jk_illumina_ref", "jk_illumina_hap", "jk_pacbio_ref", "jk_pacbio_hap",
-    "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_pacbio_ref_open", "jk_pacbio_hap_open", "jk_session_generate", "jk_session_sizes",
+    "jk_illumina_ref_job", "jk_illumina_hap_job", "jk_pacbio_ref_job", "jk_pacbio_hap_job", "jk_job_n_files", "jk_job_plan_next", "jk_job_run",
+    "jk_job_progress", "jk_job_seed_words_used", "jk_job_free",
+    "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_pacbio_ref_open", "jk_pacbio_hap_open", "jk_session_generate", "jk_session_run", "jk_session_progress", "jk_session_sizes",
     "jk_session_device_ptr", "jk_session_fetch", "jk_session_fetch_range", "jk_session_write", "jk_session_write_shard",
     "jk_session_shard_seed_words", "jk_session_timing",
     "jk_session_seed_words_used", "jk_session_retries", "jk_session_batches", "jk_session_lane_bytes", "jk_session_close",
@@ -155,7 +159,22 @@ def lib():
     L.jk_pacbio_hap.argtypes = [C.POINTER(HapSetView), C.POINTER(PacbioArgs)]
     L.jk_pacbio_ref_open.argtypes = [C.POINTER(RefGenomeView), C.POINTER(PacbioArgs), C.POINTER(C.c_void_p)]
     L.jk_pacbio_hap_open.argtypes = [C.POINTER(HapSetView), C.POINTER(PacbioArgs), C.POINTER(C.c_void_p)]
+    L.jk_illumina_ref_job.argtypes = [C.POINTER(RefGenomeView), C.POINTER(IlluminaArgs), C.POINTER(C.c_void_p)]
+    L.jk_illumina_hap_job.argtypes = [C.POINTER(HapSetView), C.POINTER(IlluminaArgs), C.POINTER(C.c_void_p)]
+    L.jk_pacbio_ref_job.argtypes = [C.POINTER(RefGenomeView), C.POINTER(PacbioArgs), C.POINTER(C.c_void_p)]
+    L.jk_pacbio_hap_job.argtypes = [C.POINTER(HapSetView), C.POINTER(PacbioArgs), C.POINTER(C.c_void_p)]
+    L.jk_job_n_files.restype = C.c_uint32
+    L.jk_job_n_files.argtypes = [C.c_void_p]
+    L.jk_job_plan_next.argtypes = [C.c_void_p]
+    L.jk_job_run.argtypes = [C.c_void_p]
+    L.jk_job_progress.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.jk_job_seed_words_used.restype = C.c_uint64
+    L.jk_job_seed_words_used.argtypes = [C.c_void_p]
+    L.jk_job_free.argtypes = [C.c_void_p]
+    L.jk_job_free.restype = None
     L.jk_session_generate.argtypes = [C.c_void_p]
+    L.jk_session_run.argtypes = [C.c_void_p]
+    L.jk_session_progress.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.jk_session_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.jk_session_device_ptr.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
     L.jk_session_fetch.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]

@@ -57,6 +57,7 @@ static void setup_model(jk_session& s, const jk_illumina_args& a) {
     s.out_prefix = a.out_prefix ? a.out_prefix : "";
     s.abort_flag = a.abort_flag;
     s.device = a.device;
+    if (a.stream_output) s.streaming = true;
     JK_HIP(hipSetDevice(s.device));
     create_generator_stream(s);
     JK_HIP(hipStreamCreateWithFlags(&s.cp_stream, hipStreamNonBlocking));
@@ -133,7 +134,7 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
         out_cap = 0; max_pool = 0; max_lanes = 0;
         uint64_t l = 0;
         while (l < s.n_shard) {
-            Batch b{l, 0, 0};
+            Batch b{l, 0, 0, 0};
             s.batch_pool_off_index.push_back(pool_off.size());
             pool_off.push_back(0);
             uint64_t used = 0;
@@ -143,7 +144,9 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
                 for (uint64_t k = 0; k < tl; k++) mx = std::max(mx, lane_cap[l + k]);
                 const uint64_t cap = align_up(mx, 4) * 64;
                 if (b.n_lanes > 0 && used + cap > max_batch) break;
-                used += cap; pool_off.push_back(used); b.n_lanes += (uint32_t)tl; l += tl;
+                used += cap; pool_off.push_back(used); b.n_lanes += (uint32_t)tl;
+                for (uint64_t k = 0; k < tl; k++) b.n_reads += lane_reads[l + k];
+                l += tl;
             }
             b.pool_bytes = used;
             out_cap += used;
@@ -161,7 +164,8 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
         if (max_pool > (8ULL << 30)) {
             size_t free_b = 0, total_b = 0;
             JK_HIP(hipMemGetInfo(&free_b, &total_b));
-            const uint64_t image = image_hint ? std::min<uint64_t>(out_cap, image_hint + image_hint / 8 + (64ULL << 20)) : out_cap;
+            uint64_t image = image_hint ? std::min<uint64_t>(out_cap, image_hint + image_hint / 8 + (64ULL << 20)) : out_cap;
+            if (s.streaming) image = 2 * max_pool;                 // two per-batch images instead of the whole run's
             const uint64_t need = (2 * max_pool + image) * s.n_ends + (16ULL << 30);
             if (need > free_b) plan(8ULL << 30);
         }
@@ -173,7 +177,7 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
         size_t free_b = 0, total_b = 0;
         JK_HIP(hipMemGetInfo(&free_b, &total_b));
         const uint64_t sets = s.batches.size() > 1 ? 2 : 1;
-        const uint64_t image = s.streaming ? 0 : out_cap;
+        const uint64_t image = s.streaming ? std::min<uint64_t>(sets, 2) * (max_pool + 64) : out_cap;
         const uint64_t need = (sets * (max_pool + 64 + CP_SLACK) + image + 64) * s.n_ends + s.n_shard * 64;
         if (need > free_b)
             throw Error(JK_ERR_DEVICE, "this run needs " + std::to_string(need >> 20) + " MiB of device memory (" +
@@ -189,12 +193,24 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     for (uint32_t e = 0; e < s.n_ends; e++) {
         s.d_pool[0][e].alloc(max_pool + 64 + CP_SLACK);
         if (s.batches.size() > 1) s.d_pool[1][e].alloc(max_pool + 64 + CP_SLACK);
-        s.d_out[e].alloc(out_cap + 64);
+        if (s.streaming) {
+            // a batch's compacted image is at most its pools' capacity (PacBio: far less; the pools hold worst-case reads)
+            s.img_cap = max_pool + 64;
+            s.d_out[e].release();
+            s.d_img[0][e].alloc(s.img_cap);
+            if (s.batches.size() > 1) s.d_img[1][e].alloc(s.img_cap); else s.d_img[1][e].release();
+        } else {
+            s.d_out[e].alloc(out_cap + 64);
+        }
         s.d_lane_bytes[e].alloc(s.n_shard * 8);
         s.d_lane_off[e].alloc(s.n_shard * 8);
         s.d_base[e].alloc((s.batches.size() + 1) * 8);
     }
     s.d_lane_made.alloc(s.n_shard * 8);
+    s.d_zero.alloc(16);
+    JK_HIP(hipMemset(s.d_zero.p, 0, 16));
+    s.progress_total = 0;
+    for (const Batch& b : s.batches) s.progress_total += b.n_reads;
     // Pool sets in rotation.  The generator fills the whole register file of every SIMD it runs on, so the compaction
     // of batch b never runs beside generator b+1 on a CU: it goes in between launches.  Measured on the headline
     // workload: 1 set 15.1 ms per step, 2 sets 14.7, 3 sets 14.7 -- two is the default (JK_POOL_SETS=1/3 to change).
@@ -285,7 +301,36 @@ static uint64_t record_max(size_t max_hdr, uint64_t max_chrom, bool paired, uint
 
 // ---- illumina_ref_cpp (src/hts_illumina.cpp:589-649): everything the reference does on the calling
 // thread before the parallel region, plus device set-up.
-static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_illumina_args& a, SeedReader& seeds) {
+static QuotaModel quota_model_ref(const jk_ref_genome& g, uint32_t n_ends) {
+    QuotaModel Q;
+    Q.n_ends = n_ends; Q.n_chroms = g.n_chroms;
+    Q.chrom_chain.emplace_back(std::vector<double>(g.chrom_lens, g.chrom_lens + g.n_chroms));
+    return Q;
+}
+// IlluminaHaplotypes::add_n_reads (src/hts_illumina.h:620-644) / PacBioHaplotypes::add_n_reads (src/hts_pacbio.h:683-700)
+static QuotaModel quota_model_hap(const jk_hap_set& hs, const std::vector<double>& hap_probs, uint32_t n_ends, bool maker_halves) {
+    const uint64_t nh = hs.n_haps, nc = hs.ref.n_chroms;
+    QuotaModel Q;
+    Q.hap = true; Q.n_ends = n_ends; Q.maker_halves = maker_halves; Q.n_haps = nh; Q.n_chroms = nc;
+    Q.hap_chain = GroupChain(hap_probs);
+    for (uint64_t h = 0; h < nh; h++) {
+        std::vector<double> cp(nc);
+        for (uint64_t c = 0; c < nc; c++) cp[c] = (double)hs.chrom_size[h * nc + c];
+        Q.chrom_chain.emplace_back(cp);
+    }
+    return Q;
+}
+// this session's lanes: planned here, or cut out of a plan made once for all devices of a one-shot call
+static LanePlan session_plan(jk_session& s, const QuotaModel& Q, const std::vector<uint64_t>& per_lane, SeedReader& seeds,
+                             bool offset_given, uint64_t offset_words, const LanePlan* full) {
+    LanePlan lp = full ? slice_plan(*full, s.n_lanes_total, s.lane_begin, s.lane_end)
+                       : plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, offset_given, offset_words);
+    s.seed_words_used = lp.words_used; s.shard_seed_begin = lp.shard_begin_word; s.shard_seed_end = lp.shard_end_word;
+    return lp;
+}
+
+static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_illumina_args& a, SeedReader& seeds,
+                              const LanePlan* full = nullptr) {
     setup_model(s, a);
     const uint32_t L = s.tables.read_length;
     const std::string barcode = (a.barcodes && a.n_barcodes > 0 && a.barcodes[0]) ? a.barcodes[0] : "";
@@ -319,11 +364,7 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
     // ---- lanes, quotas, seeds: same order of seed consumption as src/hts.h:334-353 (mt_seeds, then per lane
     // IlluminaOneGenome::add_n_reads, src/hts_illumina.h:410-418); see jk_plan.h
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, a.n_reads);
-    QuotaModel Q;
-    Q.n_ends = s.n_ends; Q.n_chroms = g.n_chroms;
-    Q.chrom_chain.emplace_back(std::vector<double>(g.chrom_lens, g.chrom_lens + g.n_chroms));
-    LanePlan lp = plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, a.seed_offset_given != 0, a.seed_offset_words);
-    s.seed_words_used = lp.words_used; s.shard_seed_begin = lp.shard_begin_word; s.shard_seed_end = lp.shard_end_word;
+    LanePlan lp = session_plan(s, quota_model_ref(g, s.n_ends), per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
     const std::vector<uint64_t>& lane_reads = lp.lane_reads;
     const std::vector<uint32_t>& lane_seeds = lp.lane_seeds;
     const ZeroArray<uint32_t>& chrom_reads = lp.quotas;
@@ -419,7 +460,7 @@ static void set_hap_params(const jk_session& s, HapDev& h, uint32_t n_haps) {
 // ---- illumina_hap_cpp (src/hts_illumina.cpp:662-739), one set of output files (sep_files handled by
 // the caller: it opens one session per haplotype with one-hot probabilities, src/hts.h:512-552).
 static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illumina_args& a,
-                              const std::vector<double>& hap_probs, uint64_t n_reads, SeedReader& seeds) {
+                              const std::vector<double>& hap_probs, uint64_t n_reads, SeedReader& seeds, const LanePlan* full = nullptr) {
     setup_model(s, a);
     s.hap = true;
     const uint32_t L = s.tables.read_length;
@@ -472,16 +513,7 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
     // each read maker's own add_n_reads (halves the pair count again when paired; its result is never
     // read by the haplotype path, but it consumes 8 seed words when it has reads).  See jk_plan.h.
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, n_reads);
-    QuotaModel Q;
-    Q.hap = true; Q.n_ends = s.n_ends; Q.maker_halves = s.paired; Q.n_haps = nh; Q.n_chroms = nc;
-    Q.hap_chain = GroupChain(hap_probs);
-    for (uint64_t h = 0; h < nh; h++) {
-        std::vector<double> cp(nc);
-        for (uint64_t c = 0; c < nc; c++) cp[c] = (double)cell_size[h * nc + c];
-        Q.chrom_chain.emplace_back(cp);
-    }
-    LanePlan lp = plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, a.seed_offset_given != 0, a.seed_offset_words);
-    s.seed_words_used = lp.words_used; s.shard_seed_begin = lp.shard_begin_word; s.shard_seed_end = lp.shard_end_word;
+    LanePlan lp = session_plan(s, quota_model_hap(hs, hap_probs, s.n_ends, s.paired), per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
     const std::vector<uint64_t>& lane_reads = lp.lane_reads;
     const std::vector<uint32_t>& lane_seeds = lp.lane_seeds;
     const ZeroArray<uint32_t>& vc = lp.quotas;

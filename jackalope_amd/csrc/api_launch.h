@@ -4,18 +4,95 @@
 
 namespace jk {
 
-static void launch_generate(jk_session& s) {
+// Sink side of a streaming run: one thread takes the batches' images in order as their compaction completes and
+// hands them to the files (device BGZF where asked for, pinned double-buffered D2H, file writes on writer threads),
+// while the calling thread keeps the generator launches coming.  An image slot is reused two batches later, once its
+// bytes have left the device.
+struct StreamCtx {
+    jk_session& s;
+    HostPipe pipe;
+    std::vector<std::unique_ptr<FastqFile>> files;
+    std::mutex m; std::condition_variable cv;
+    std::deque<int> q; bool closed = false;
+    int consumed = -1;                   // last batch whose image has left the device
+    int err_code = 0; std::string err;
+    std::thread th;
+    StreamCtx(jk_session& s_, const std::string& suffix) : s(s_), pipe(PIPE_PIECE, 6, pipe_writers()) {
+        for (uint32_t e = 0; e < s.n_ends; e++) files.emplace_back(new FastqFile(s, e, suffix));
+        th = std::thread([this] { run(); });
+    }
+    ~StreamCtx() { close(); }
+    void push(int b) { { std::lock_guard<std::mutex> l(m); q.push_back(b); } cv.notify_all(); }
+    void close() {
+        { std::lock_guard<std::mutex> l(m); closed = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    // wait until batch `b`'s image slot may be overwritten; false = the sink failed
+    bool wait_consumed(int b) {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return consumed >= b || err_code != 0; });
+        return err_code == 0;
+    }
+    void fail(int code, const std::string& what) {
+        { std::lock_guard<std::mutex> l(m); if (!err_code) { err_code = code; err = what; } }
+        cv.notify_all();
+    }
+    void run() {
+        try {
+            JK_HIP(hipSetDevice(s.device));
+            for (;;) {
+                int b;
+                {
+                    std::unique_lock<std::mutex> l(m);
+                    cv.wait(l, [&] { return closed || !q.empty() || err_code != 0; });
+                    if (err_code != 0 || q.empty()) return;
+                    b = q.front(); q.pop_front();
+                }
+                JK_HIP(hipEventSynchronize(s.cp_done[b]));
+                uint32_t kerr = 0;
+                JK_HIP(hipMemcpyAsync(&kerr, s.d_err.p, 4, hipMemcpyDeviceToHost, pipe.stream()));
+                uint64_t base[2][2] = {{0, 0}, {0, 0}};
+                for (uint32_t e = 0; e < s.n_ends; e++)
+                    JK_HIP(hipMemcpyAsync(base[e], s.d_base[e].as<uint64_t>() + b, 16, hipMemcpyDeviceToHost, pipe.stream()));
+                JK_HIP(hipStreamSynchronize(pipe.stream()));
+                if (kerr) { fail(JK_ERR_DEVICE, "kernel error"); return; }      // (the caller reads the bits and words the message)
+                const int slot = b & 1;
+                for (uint32_t e = 0; e < s.n_ends; e++)
+                    files[e]->add(pipe, s.d_img[slot][e].as<uint8_t>(), base[e][1] - base[e][0]);
+                s.progress_done.fetch_add(s.batches[b].n_reads);
+                { std::lock_guard<std::mutex> l(m); consumed = b; }
+                cv.notify_all();
+            }
+        } catch (const Error& e) { fail(e.code, e.what()); }
+        catch (const std::exception& e) { fail(JK_ERR_IO, e.what()); }
+    }
+};
+
+// One pass over all batches of the session.  `sc` == nullptr: the images of all batches end up side by side in the
+// resident image (d_out).  Otherwise every batch's image goes to one of two per-batch buffers and on to the sink.
+static void launch_batches(jk_session& s, StreamCtx* sc) {
     JK_HIP(hipSetDevice(s.device));
     JK_HIP(hipMemsetAsync(s.d_err.p, 0, 4, s.stream));
     for (uint32_t e = 0; e < s.n_ends; e++) JK_HIP(hipMemsetAsync(s.d_base[e].p, 0, 8, s.stream));
+    s.progress_done.store(0);
     size_t ev = 0;
     JK_HIP(hipEventRecord(s.events[ev++], s.stream));
     JK_HIP(hipStreamWaitEvent(s.cp_stream, s.events[0], 0));
+    bool stopped = false;
     for (size_t b = 0; b < s.batches.size(); b++) {
-        if (s.abort_flag && *s.abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
+        if (s.abort_flag && *s.abort_flag) { stopped = true; break; }
         const Batch& B = s.batches[b];
         const int pp = (int)(b % (size_t)s.n_pool_sets);       // pool set in rotation
         const size_t ns = (size_t)s.n_pool_sets;
+        const int slot = (int)(b & 1);
+        // where this batch's compacted image goes
+        uint8_t* out_img[2]; const uint64_t* out_base[2]; uint64_t out_cap;
+        for (uint32_t e = 0; e < 2; e++) {
+            out_img[e] = e < s.n_ends ? (sc ? s.d_img[slot][e].as<uint8_t>() : s.d_out[e].as<uint8_t>()) : nullptr;
+            out_base[e] = e < s.n_ends ? (sc ? s.d_zero.as<uint64_t>() : s.d_base[e].as<uint64_t>() + b) : nullptr;
+        }
+        out_cap = sc ? s.img_cap : s.out_cap;
         if (s.pacbio) {
             PacbioKernelParams Q = s.kpb;
             Q.n_lanes = B.n_lanes;
@@ -35,6 +112,7 @@ static void launch_generate(jk_session& s) {
             JK_HIP(hipGetLastError());
             JK_HIP(hipEventRecord(s.events[ev++], s.stream));
             JK_HIP(hipEventRecord(s.gen_done[b], s.stream));
+            if (sc && b >= 2 && !sc->wait_consumed((int)b - 2)) { stopped = true; break; }
             JK_HIP(hipStreamWaitEvent(s.cp_stream, s.gen_done[b], 0));
             const uint32_t nbp = (B.n_lanes + SCAN_BLOCK - 1) / SCAN_BLOCK;
             uint64_t* lb = s.d_lane_bytes[0].as<uint64_t>() + B.lane0;
@@ -45,10 +123,11 @@ static void launch_generate(jk_session& s) {
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.cp_stream, bs, nbp, base);
             hipLaunchKernelGGL(scan_add_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lo, bs, B.n_lanes);
             hipLaunchKernelGGL(compact_linear_kernel, dim3(B.n_lanes), dim3(256), 0, s.cp_stream,
-                               s.d_pool[pp][0].as<uint8_t>(), Q.pool_off, lb, lo, s.d_out[0].as<uint8_t>(), base, B.n_lanes,
-                               s.out_cap, s.d_err.as<uint32_t>());
+                               s.d_pool[pp][0].as<uint8_t>(), Q.pool_off, lb, lo, out_img[0], out_base[0], B.n_lanes,
+                               out_cap, s.d_err.as<uint32_t>());
             JK_HIP(hipGetLastError());
             JK_HIP(hipEventRecord(s.cp_done[b], s.cp_stream));
+            if (sc) sc->push((int)b);
             continue;
         }
         IlluminaKernelParams P = s.kp;
@@ -69,9 +148,6 @@ static void launch_generate(jk_session& s) {
         // workgroups then take over CUs as the current batch's finish instead of waiting for its slowest one.
         hipStream_t gs = (s.two_gen_streams && (b & 1)) ? s.stream2 : s.stream;
         if (s.two_gen_streams && b == 1) JK_HIP(hipStreamWaitEvent(s.stream2, s.events[0], 0));
-#ifndef JK_ILL_BLOCK
-#define JK_ILL_BLOCK 1024
-#endif
         const uint32_t block = JK_ILL_BLOCK;
         const uint32_t grid = (B.n_lanes + block - 1) / block;
         // the pool set is free again once the compaction of batch b-2 has read it
@@ -89,6 +165,7 @@ static void launch_generate(jk_session& s) {
         JK_HIP(hipGetLastError());
         JK_HIP(hipEventRecord(s.events[ev++], gs));
         JK_HIP(hipEventRecord(s.gen_done[b], gs));
+        if (sc && b >= 2 && !sc->wait_consumed((int)b - 2)) { stopped = true; break; }
         JK_HIP(hipStreamWaitEvent(s.cp_stream, s.gen_done[b], 0));
         const uint32_t nb = (B.n_lanes + SCAN_BLOCK - 1) / SCAN_BLOCK;
         for (uint32_t e = 0; e < s.n_ends; e++) {
@@ -100,21 +177,29 @@ static void launch_generate(jk_session& s) {
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.cp_stream, bs, nb, base);
             hipLaunchKernelGGL(scan_add_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, s.cp_stream, lo, bs, B.n_lanes);
             hipLaunchKernelGGL(compact_pools_kernel, dim3((B.n_lanes + 63) / 64), dim3(CP_THREADS), 0, s.cp_stream,
-                               s.d_pool[pp][e].as<uint8_t>(), P.pool_off, lb, lo, s.d_out[e].as<uint8_t>(), base, B.n_lanes);
+                               s.d_pool[pp][e].as<uint8_t>(), P.pool_off, lb, lo, out_img[e], out_base[e], B.n_lanes);
             JK_HIP(hipGetLastError());
         }
         JK_HIP(hipEventRecord(s.cp_done[b], s.cp_stream));
+        if (sc) sc->push((int)b);
     }
-    if (!s.batches.empty()) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[s.batches.size() - 1], 0));
+    if (stopped) {
+        (void)hipStreamSynchronize(s.stream); (void)hipStreamSynchronize(s.cp_stream);
+        if (s.stream2) (void)hipStreamSynchronize(s.stream2);
+        if (sc) sc->close();
+        if (s.abort_flag && *s.abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
+    }
+    if (!stopped && !s.batches.empty()) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[s.batches.size() - 1], 0));
     if (!s.d_result.p) s.d_result.alloc(32);
     JK_HIP(hipMemsetAsync(s.d_result.p, 0, 32, s.stream));
     hipLaunchKernelGGL(finish_kernel, dim3(64), dim3(256), 0, s.stream, s.d_lane_made.as<uint64_t>(), (uint64_t)s.n_shard, s.d_err.as<uint32_t>(),
                        s.d_base[0].as<uint64_t>() + s.batches.size(),
                        s.n_ends > 1 ? s.d_base[1].as<uint64_t>() + s.batches.size() : (const uint64_t*)nullptr, s.d_result.as<uint64_t>());
     JK_HIP(hipGetLastError());
-    JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+    if (!stopped) JK_HIP(hipEventRecord(s.events[ev++], s.stream));
     JK_HIP(hipStreamSynchronize(s.stream));
     JK_HIP(hipStreamSynchronize(s.cp_stream));
+    if (sc) sc->close();               // the sink has taken every batch it was given (or failed)
 
     uint64_t result[4] = {0, 0, 0, 0};
     JK_HIP(hipMemcpy(result, s.d_result.p, sizeof(result), hipMemcpyDeviceToHost));
@@ -130,6 +215,8 @@ static void launch_generate(jk_session& s) {
     if ((err & JK_KERR_POOL_OVERFLOW) && s.pacbio) throw Error(JK_ERR_RETRY, "pool overflow");
     if (err & JK_KERR_POOL_OVERFLOW) throw Error(JK_ERR_DEVICE, "internal error: a lane overflowed its pool region");
     if (err & JK_KERR_TOO_MANY_DELETIONS) throw Error(JK_ERR_UNSUPPORTED, "a read needed more than 2x read_length reference positions (deletion probability too high for the GPU path)");
+    if (sc && sc->err_code) throw Error(sc->err_code, sc->err);
+    if (stopped) throw Error(JK_ERR_DEVICE, "the run stopped early");
     for (uint32_t e = 0; e < s.n_ends; e++) s.bytes[e] = result[1 + e];
     s.reads_made = result[3];
     float t = 0;
@@ -141,7 +228,28 @@ static void launch_generate(jk_session& s) {
     JK_HIP(hipEventElapsedTime(&t, s.events[0], s.events[ev - 1]));
     rest = t - gen;
     s.ms[0] = gen; s.ms[1] = rest; s.ms[2] = t;
+    s.progress_done.store(s.progress_total);
+}
+
+// generate(): all batches into the resident image
+static void launch_generate(jk_session& s) {
+    if (s.streaming) throw Error(JK_ERR_ARG, "this session streams its output (stream_output): use jk_session_run");
+    launch_batches(s, nullptr);
     s.generated = true;
+}
+
+// run(): all batches through the sink into <out_prefix>_R<e>.fq[.gz]<suffix>; `with_eof` = 0 leaves a BGZF file
+// open-ended (another part is appended behind it)
+static void launch_stream(jk_session& s, const std::string& suffix = "", bool with_eof = true, uint64_t* file_bytes = nullptr) {
+    if (!s.streaming) throw Error(JK_ERR_ARG, "jk_session_run needs a session opened with stream_output");
+    StreamCtx sc(s, suffix);
+    launch_batches(s, &sc);
+    for (uint32_t e = 0; e < s.n_ends; e++) {
+        if (sc.files[e]->plain_bytes() != s.bytes[e]) throw Error(JK_ERR_DEVICE, "internal error: streamed bytes differ from the generated total");
+        sc.files[e]->finish(sc.pipe, with_eof);
+        if (file_bytes) file_bytes[e] = sc.files[e]->bytes_written();
+    }
+    s.streamed = true;
 }
 
 }  // namespace jk

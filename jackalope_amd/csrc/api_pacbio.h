@@ -23,6 +23,7 @@ static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a
     s.out_prefix = a.out_prefix ? a.out_prefix : "";
     s.abort_flag = a.abort_flag;
     s.device = a.device;
+    if (a.stream_output) s.streaming = true;
     JK_HIP(hipSetDevice(s.device));
     create_generator_stream(s);
     JK_HIP(hipStreamCreateWithFlags(&s.cp_stream, hipStreamNonBlocking));
@@ -174,7 +175,7 @@ static void upload_headers(jk_session& s, const std::vector<std::string>& hdrs, 
     s.d_hdr_off.upload(hoff);
 }
 
-static void open_pacbio_ref(jk_session& s, const jk_ref_genome& g, const jk_pacbio_args& a, SeedReader& seeds) {
+static void open_pacbio_ref(jk_session& s, const jk_ref_genome& g, const jk_pacbio_args& a, SeedReader& seeds, const LanePlan* full = nullptr) {
     uint64_t max_chrom = 0;
     for (uint64_t i = 0; i < g.n_chroms; i++) max_chrom = std::max<uint64_t>(max_chrom, g.chrom_lens[i]);
     PacbioHostModel M = setup_pacbio_model(s, a, max_chrom);
@@ -186,11 +187,7 @@ static void open_pacbio_ref(jk_session& s, const jk_ref_genome& g, const jk_pacb
     upload_headers(s, hdrs, max_hdr);
     // lanes, quotas, seeds (src/hts.h:334-353 with n_read_ends = 1; PacBioOneGenome::add_n_reads, hts_pacbio.h:499-503)
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, a.n_reads);
-    QuotaModel Q;
-    Q.n_ends = 1; Q.n_chroms = g.n_chroms;
-    Q.chrom_chain.emplace_back(std::vector<double>(g.chrom_lens, g.chrom_lens + g.n_chroms));
-    LanePlan lp = plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, a.seed_offset_given != 0, a.seed_offset_words);
-    s.seed_words_used = lp.words_used; s.shard_seed_begin = lp.shard_begin_word; s.shard_seed_end = lp.shard_end_word;
+    LanePlan lp = session_plan(s, quota_model_ref(g, 1), per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
     std::shared_ptr<LanePlan> plan = std::make_shared<LanePlan>(std::move(lp));
     const uint64_t mbb = a.max_batch_bytes;
     jk_session* sp = &s;
@@ -199,7 +196,7 @@ static void open_pacbio_ref(jk_session& s, const jk_ref_genome& g, const jk_pacb
 }
 
 static void open_pacbio_hap(jk_session& s, const jk_hap_set& hs, const jk_pacbio_args& a,
-                            const std::vector<double>& hap_probs, uint64_t n_reads, SeedReader& seeds) {
+                            const std::vector<double>& hap_probs, uint64_t n_reads, SeedReader& seeds, const LanePlan* full = nullptr) {
     const uint64_t nh = hs.n_haps, nc = hs.ref.n_chroms;
     if (nh == 0 || nc == 0) throw Error(JK_ERR_ARG, "haplotype set is empty");
     if (hap_probs.size() != nh) throw Error(JK_ERR_ARG, "haplotype_probs must have one entry per haplotype");
@@ -222,16 +219,7 @@ static void open_pacbio_hap(jk_session& s, const jk_hap_set& hs, const jk_pacbio
     upload_headers(s, hdrs, max_hdr);
     // PacBioHaplotypes::add_n_reads (src/hts_pacbio.h:683-700)
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, n_reads);
-    QuotaModel Q;
-    Q.hap = true; Q.n_ends = 1; Q.maker_halves = false; Q.n_haps = nh; Q.n_chroms = nc;
-    Q.hap_chain = GroupChain(hap_probs);
-    for (uint64_t h = 0; h < nh; h++) {
-        std::vector<double> cp(nc);
-        for (uint64_t c = 0; c < nc; c++) cp[c] = (double)cell_size[h * nc + c];
-        Q.chrom_chain.emplace_back(cp);
-    }
-    LanePlan lp = plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, a.seed_offset_given != 0, a.seed_offset_words);
-    s.seed_words_used = lp.words_used; s.shard_seed_begin = lp.shard_begin_word; s.shard_seed_end = lp.shard_end_word;
+    LanePlan lp = session_plan(s, quota_model_hap(hs, hap_probs, 1, false), per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
     std::shared_ptr<LanePlan> plan = std::make_shared<LanePlan>(std::move(lp));
     set_hap_params(s, s.kpb.h, (uint32_t)nh);
     const uint64_t mbb = a.max_batch_bytes;

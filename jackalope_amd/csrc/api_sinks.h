@@ -2,6 +2,10 @@
 // (part of the one translation unit jk_api.hip; see the include list there)
 #pragma once
 
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+
 namespace jk {
 
 // ---- output sinks (src/io.h:58-295): plain file, gzip (zlib gzFile) or BGZF ---------------------------
@@ -42,8 +46,10 @@ static uint64_t bgzf_bound(uint64_t n) {
 
 struct BgzfDeviceTables { DevBuf crc, x512, x8; };
 static BgzfTables bgzf_tables(int device) {
+    static std::mutex mu;
     static std::vector<std::unique_ptr<BgzfDeviceTables>> per_device(64);
     if (device < 0 || device >= 64) throw Error(JK_ERR_ARG, "bad device ordinal");
+    std::lock_guard<std::mutex> lock(mu);
     if (!per_device[device]) {
         std::vector<uint32_t> crc(4 * 256), x512(1024), x8(64);
         for (uint32_t i = 0; i < 256; i++) {
@@ -71,10 +77,24 @@ static BgzfTables bgzf_tables(int device) {
     return T;
 }
 
-// d_src[0..n) -> complete BGZF file image (blocks + end-of-file block) at d_dst; returns its size.
-// Works through the input in groups of blocks so that the slot scratch stays at 512 MiB.
+struct EventPair {       // a timing pair that cannot leak when a HIP call between create and destroy throws
+    hipEvent_t a = nullptr, b = nullptr;
+    EventPair() {
+        JK_HIP(hipEventCreate(&a));
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); throw Error(JK_ERR_DEVICE, "hipEventCreate failed"); }
+    }
+    EventPair(const EventPair&) = delete;
+    EventPair& operator=(const EventPair&) = delete;
+    ~EventPair() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    double ms() const { float t = 0; JK_HIP(hipEventElapsedTime(&t, a, b)); return t; }
+};
+
+// d_src[0..n) -> BGZF blocks (+ the end-of-file block when `with_eof`) at d_dst; returns the size.
+// Works through the input in groups of blocks so that the slot scratch stays at 512 MiB.  A streamed file is
+// made of several such pieces (one per generator launch, the last block of each shorter than 0xff00), closed
+// by one end-of-file block.
 static uint64_t bgzf_deflate_device(int device, hipStream_t stream, const uint8_t* d_src, uint64_t n, uint8_t* d_dst,
-                                    uint64_t cap, double* ms) {
+                                    uint64_t cap, double* ms, bool with_eof = true) {
     if (reinterpret_cast<uintptr_t>(d_src) & 15u) throw Error(JK_ERR_ARG, "BGZF input must be 16-byte aligned");
     if (cap < bgzf_bound(n)) throw Error(JK_ERR_ARG, "BGZF destination smaller than jk_bgzf_bound()");
     const BgzfTables T = bgzf_tables(device);
@@ -88,9 +108,8 @@ static uint64_t bgzf_deflate_device(int device, hipStream_t stream, const uint8_
     sums.alloc(((g_blocks + SCAN_BLOCK - 1) / SCAN_BLOCK) * 8);
     base.alloc((n_groups + 1) * 8);
     JK_HIP(hipMemsetAsync(base.p, 0, (n_groups + 1) * 8, stream));
-    hipEvent_t e0, e1;
-    JK_HIP(hipEventCreate(&e0)); JK_HIP(hipEventCreate(&e1));
-    JK_HIP(hipEventRecord(e0, stream));
+    EventPair ev;
+    JK_HIP(hipEventRecord(ev.a, stream));
     for (uint64_t g = 0; g < n_groups; g++) {
         const uint64_t b0 = g * GROUP;
         const uint32_t nb = (uint32_t)std::min<uint64_t>(GROUP, n_blocks - b0);
@@ -106,111 +125,172 @@ static uint64_t bgzf_deflate_device(int device, hipStream_t stream, const uint8_
                            offs.as<uint64_t>(), d_dst, base.as<uint64_t>() + g);
     }
     JK_HIP(hipGetLastError());
-    JK_HIP(hipEventRecord(e1, stream));
+    JK_HIP(hipEventRecord(ev.b, stream));
     uint64_t total = 0;
     JK_HIP(hipMemcpyAsync(&total, base.as<uint64_t>() + n_groups, 8, hipMemcpyDeviceToHost, stream));
     JK_HIP(hipStreamSynchronize(stream));
-    JK_HIP(hipMemcpy(d_dst + total, kBgzfEof, sizeof(kBgzfEof), hipMemcpyHostToDevice));
-    if (ms) { float t = 0; JK_HIP(hipEventElapsedTime(&t, e0, e1)); *ms = t; }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return total + sizeof(kBgzfEof);
+    if (with_eof) JK_HIP(hipMemcpy(d_dst + total, kBgzfEof, sizeof(kBgzfEof), hipMemcpyHostToDevice));
+    if (ms) *ms = ev.ms();
+    return total + (with_eof ? sizeof(kBgzfEof) : 0);
 }
 
-// Device image -> host consumer through two pinned buffers: the copy of piece k+1 runs while `sink`
-// works on piece k (file write, zlib).  `piece` is a whole number of BGZF input blocks.
-template <typename Sink>
-static void stream_to_host(const uint8_t* d_src, uint64_t n, size_t piece, Sink&& sink) {
-    struct Pinned {
-        void* p[2] = {nullptr, nullptr};
-        hipStream_t st = nullptr;
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        ~Pinned() {
-            for (int k = 0; k < 2; k++) { if (p[k]) (void)hipHostFree(p[k]); if (ev[k]) (void)hipEventDestroy(ev[k]); }
-            if (st) (void)hipStreamDestroy(st);
-        }
-    } P;
-    if (n == 0) return;
-    piece = (size_t)std::min<uint64_t>(piece, n);
-    JK_HIP(hipStreamCreateWithFlags(&P.st, hipStreamNonBlocking));
-    for (int k = 0; k < 2; k++) { JK_HIP(hipHostMalloc(&P.p[k], piece, hipHostMallocDefault)); JK_HIP(hipEventCreate(&P.ev[k])); }
-    const uint64_t n_pieces = (n + piece - 1) / piece;
-    auto issue = [&](uint64_t k) {
-        const uint64_t off = k * piece;
-        JK_HIP(hipMemcpyAsync(P.p[k & 1], d_src + off, (size_t)std::min<uint64_t>(piece, n - off), hipMemcpyDeviceToHost, P.st));
-        JK_HIP(hipEventRecord(P.ev[k & 1], P.st));
-    };
-    issue(0);
-    for (uint64_t k = 0; k < n_pieces; k++) {
-        JK_HIP(hipEventSynchronize(P.ev[k & 1]));
-        if (k + 1 < n_pieces) issue(k + 1);
-        sink(static_cast<const uint8_t*>(P.p[k & 1]), (size_t)std::min<uint64_t>(piece, n - k * piece));
-    }
-}
-
-// A lane shard's image at its place in the shared file (see jk_session_write_shard).
-static void write_shard(const jk_session& s, const uint64_t* file_offset) {
-    if (!s.generated) throw Error(JK_ERR_ARG, "jk_session_write_shard before jk_session_generate");
-    if (s.compress > 0) throw Error(JK_ERR_UNSUPPORTED, "lane shards write uncompressed FASTQ only (compress the assembled file, or give each rank its own out_prefix)");
-    for (uint32_t e = 0; e < s.n_ends; e++) {
-        const std::string fn = s.out_prefix + "_R" + std::to_string(e + 1) + ".fq";
-        struct Fd { int fd = -1; ~Fd() { if (fd >= 0) ::close(fd); } } F;
-        F.fd = ::open(fn.c_str(), O_WRONLY | O_CREAT, 0644);
-        if (F.fd < 0) throw Error(JK_ERR_IO, "Unable to open file " + fn + ".\n");
-        uint64_t at = file_offset[e];
-        stream_to_host(s.d_out[e].as<uint8_t>(), s.bytes[e], BGZF_IN * 1024, [&](const uint8_t* p, size_t n) {
-            while (n) {
-                const ssize_t w = ::pwrite(F.fd, p, n, (off_t)at);
-                if (w < 0) { if (errno == EINTR) continue; throw Error(JK_ERR_IO, "write to " + fn + " failed"); }
-                p += w; n -= (size_t)w; at += (uint64_t)w;
+// ---- device bytes -> host consumers -------------------------------------------------------------------
+// A ring of pinned buffers.  copy() cuts a device range into pieces, keeps two D2H copies in flight and hands every
+// finished piece to `consume`: on the calling thread, in order (a gzip stream), or on a small pool of writer threads
+// (pwrite at known offsets: the file write of one piece overlaps the copies and writes of the others).
+class HostPipe {
+public:
+    using Consume = std::function<void(const uint8_t*, size_t, uint64_t)>;    // (bytes, count, offset of the piece in the range)
+    HostPipe(size_t piece_bytes, int n_buffers, int n_workers) : piece_(piece_bytes), nb_(n_buffers) {
+        buf_.assign(nb_, nullptr); ev_.assign(nb_, nullptr); busy_.assign(nb_, 0);
+        try {
+            JK_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+            for (int k = 0; k < nb_; k++) {
+                JK_HIP(hipHostMalloc(&buf_[k], piece_, hipHostMallocDefault));
+                JK_HIP(hipEventCreateWithFlags(&ev_[k], hipEventDisableTiming));
             }
-        });
-        const int fd = F.fd; F.fd = -1;
-        if (::close(fd) != 0) throw Error(JK_ERR_IO, "error closing " + fn);
+        } catch (...) { free_all(); throw; }
+        for (int w = 0; w < n_workers; w++) workers_.emplace_back([this] { work(); });
     }
-}
+    HostPipe(const HostPipe&) = delete;
+    HostPipe& operator=(const HostPipe&) = delete;
+    ~HostPipe() {
+        { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+        cv_.notify_all();
+        for (std::thread& t : workers_) t.join();
+        free_all();
+    }
+    size_t piece() const { return piece_; }
+    hipStream_t stream() const { return st_; }
+    // `ordered`: consume on this thread, piece after piece; else on the workers (consume must be thread-safe)
+    void copy(const uint8_t* d_src, uint64_t n, const Consume& consume, bool ordered) {
+        struct Fl { int k; size_t n; uint64_t off; };
+        std::deque<Fl> flight;
+        auto land = [&]() {
+            const Fl f = flight.front(); flight.pop_front();
+            JK_HIP(hipEventSynchronize(ev_[f.k]));
+            if (ordered || workers_.empty()) {
+                struct Release { HostPipe* p; int k; ~Release() { p->release(k); } } rel{this, f.k};
+                consume(static_cast<const uint8_t*>(buf_[f.k]), f.n, f.off);
+            } else {
+                { std::lock_guard<std::mutex> l(m_); tasks_.push_back(Task{f.k, f.n, f.off, consume}); }
+                cv_.notify_all();
+            }
+        };
+        try {
+            for (uint64_t off = 0; off < n; off += piece_) {
+                const size_t cnt = (size_t)std::min<uint64_t>(piece_, n - off);
+                const int k = acquire();
+                flight.push_back(Fl{k, cnt, off});
+                JK_HIP(hipMemcpyAsync(buf_[k], d_src + off, cnt, hipMemcpyDeviceToHost, st_));
+                JK_HIP(hipEventRecord(ev_[k], st_));
+                if (flight.size() >= 2) land();
+            }
+            while (!flight.empty()) land();
+        } catch (...) {
+            (void)hipStreamSynchronize(st_);
+            for (const Fl& f : flight) release(f.k);
+            throw;
+        }
+    }
+    // wait until the workers have consumed everything handed to them; rethrows their first error
+    void drain() {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return tasks_.empty() && running_ == 0; });
+        if (!err_.empty()) { const std::string e = err_; err_.clear(); throw Error(JK_ERR_IO, e); }
+    }
+private:
+    struct Task { int k; size_t n; uint64_t off; Consume fn; };
+    void free_all() {
+        for (int k = 0; k < nb_; k++) { if (buf_[k]) (void)hipHostFree(buf_[k]); if (ev_[k]) (void)hipEventDestroy(ev_[k]); }
+        if (st_) (void)hipStreamDestroy(st_);
+    }
+    int acquire() {
+        std::unique_lock<std::mutex> l(m_);
+        for (;;) {
+            if (!err_.empty()) { const std::string e = err_; throw Error(JK_ERR_IO, e); }
+            for (int k = 0; k < nb_; k++) if (!busy_[k]) { busy_[k] = 1; return k; }
+            cv_.wait(l);
+        }
+    }
+    void release(int k) { { std::lock_guard<std::mutex> l(m_); busy_[k] = 0; } cv_.notify_all(); }
+    void work() {
+        for (;;) {
+            Task t;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return stop_ || !tasks_.empty(); });
+                if (tasks_.empty()) return;
+                t = tasks_.front(); tasks_.pop_front(); running_++;
+            }
+            std::string e;
+            try { t.fn(static_cast<const uint8_t*>(buf_[t.k]), t.n, t.off); } catch (const std::exception& ex) { e = ex.what(); }
+            { std::lock_guard<std::mutex> l(m_); busy_[t.k] = 0; running_--; if (!e.empty() && err_.empty()) err_ = e; }
+            cv_.notify_all();
+        }
+    }
+    size_t piece_; int nb_;
+    hipStream_t st_ = nullptr;
+    std::vector<void*> buf_; std::vector<hipEvent_t> ev_; std::vector<char> busy_;
+    std::mutex m_; std::condition_variable cv_;
+    std::deque<Task> tasks_; int running_ = 0; bool stop_ = false; std::string err_;
+    std::vector<std::thread> workers_;
+};
 
-static void write_files(const jk_session& s) {
-    if (!s.generated) throw Error(JK_ERR_ARG, "jk_session_write before jk_session_generate");
-    if (s.n_shard != s.n_lanes_total)
-        throw Error(JK_ERR_UNSUPPORTED, "this session holds lanes " + std::to_string(s.lane_begin) + ".." + std::to_string(s.lane_end) + " of " +
-                    std::to_string(s.n_lanes_total) + ": writing it as the whole file would drop the other lanes' reads -- use "
-                    "jk_session_write_shard with the byte offsets from the ranks' jk_session_sizes");
-    const size_t CH = BGZF_IN * 1024;                     // 66.8 MB, a whole number of BGZF blocks
-    const unsigned n_thr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    for (uint32_t e = 0; e < s.n_ends; e++) {
-        std::string fn = s.out_prefix + "_R" + std::to_string(e + 1) + ".fq";
-        if (s.compress > 0) fn += ".gz";
-        struct Files {
-            FILE* f = nullptr; gzFile gz = nullptr;
-            ~Files() { if (f) std::fclose(f); if (gz) gzclose(gz); }
-        } F;
+// One output file of a run (one read end): takes the FASTQ image piece by piece -- the whole resident image of a
+// session, or one generator launch after the other of a streaming run -- and writes <prefix>_R<e>.fq[.gz].
+//   plain        every piece at its byte offset (pwrite on the pipe's writer threads)
+//   bgzip        BGZF blocks made on the device; only compressed bytes cross the host link
+//   bgzip-host   BGZF blocks deflated by zlib on host threads at the requested level
+//   gzip         one gzip stream (gzwrite), in order
+// A session with out_prefix == "" is a null sink: the bytes are brought to the host (compressed first when asked for)
+// and dropped (bench.py times the D2H-inclusive rate with it).
+class FastqFile {
+public:
+    FastqFile(const jk_session& s, uint32_t end, const std::string& suffix = "", bool truncate = true, uint64_t base_offset = 0)
+        : s_(s), at_(base_offset) {
+        null_ = s.out_prefix.empty();
+        fn_ = s.out_prefix + "_R" + std::to_string(end + 1) + ".fq" + (s.compress > 0 ? ".gz" : "") + suffix;
+        if (null_) return;
         if (s.compress > 0 && !s.bgzip) {
             const std::string mode = "wb" + std::to_string(s.compress);
-            F.gz = gzopen(fn.c_str(), mode.c_str());
-            if (!F.gz) throw Error(JK_ERR_IO, "gzopen of " + fn + " failed.\n");
+            gz_ = gzopen(fn_.c_str(), mode.c_str());
+            if (!gz_) throw Error(JK_ERR_IO, "gzopen of " + fn_ + " failed.\n");
         } else {
-            F.f = std::fopen(fn.c_str(), "wb");
-            if (!F.f) throw Error(JK_ERR_IO, "Unable to open file " + fn + ".\n");
+            fd_ = ::open(fn_.c_str(), O_WRONLY | O_CREAT | (truncate ? O_TRUNC : 0), 0644);
+            if (fd_ < 0) throw Error(JK_ERR_IO, "Unable to open file " + fn_ + ".\n");
         }
-        auto put = [&](const uint8_t* p, size_t n) {
-            if (std::fwrite(p, 1, n, F.f) != n) throw Error(JK_ERR_IO, "short write to " + fn);
-        };
-        const uint8_t* d_img = s.d_out[e].as<uint8_t>();
-        if (s.compress == 0) {
-            stream_to_host(d_img, s.bytes[e], CH, put);
-        } else if (!s.bgzip) {
-            stream_to_host(d_img, s.bytes[e], CH, [&](const uint8_t* p, size_t n) {
-                if (gzwrite(F.gz, p, (unsigned)n) != (int)n) throw Error(JK_ERR_IO, "gzwrite to " + fn + " failed");
-            });
-        } else if (!s.host_deflate) {
-            // BGZF blocks made on the device; only the compressed image crosses the host link
-            DevBuf comp;
-            comp.alloc(bgzf_bound(s.bytes[e]));
-            const uint64_t n_comp = bgzf_deflate_device(s.device, s.stream, d_img, s.bytes[e], comp.as<uint8_t>(), comp.n, nullptr);
-            stream_to_host(comp.as<uint8_t>(), n_comp, CH, put);
+    }
+    FastqFile(const FastqFile&) = delete;
+    FastqFile& operator=(const FastqFile&) = delete;
+    ~FastqFile() { if (fd_ >= 0) ::close(fd_); if (gz_) gzclose(gz_); }
+
+    // n bytes of FASTQ at d_img (device); pieces of one file must be added in file order
+    void add(HostPipe& pipe, const uint8_t* d_img, uint64_t n) {
+        if (n == 0) return;
+        plain_ += n;
+        const int fd = fd_; const std::string fn = fn_; const bool null = null_;
+        if (s_.compress == 0) {
+            const uint64_t at = at_;
+            at_ += n;
+            if (null) pipe.copy(d_img, n, [](const uint8_t*, size_t, uint64_t) {}, true);
+            else pipe.copy(d_img, n, [fd, fn, at](const uint8_t* p, size_t cnt, uint64_t off) { pwrite_all(fd, fn, p, cnt, at + off); }, false);
+        } else if (!s_.bgzip) {
+            pipe.copy(d_img, n, [&](const uint8_t* p, size_t cnt, uint64_t) {
+                if (!null_ && gzwrite(gz_, p, (unsigned)cnt) != (int)cnt) throw Error(JK_ERR_IO, "gzwrite to " + fn_ + " failed");
+            }, true);
+        } else if (!s_.host_deflate) {
+            if (comp_.n < bgzf_bound(n)) comp_.alloc(bgzf_bound(n) + (bgzf_bound(n) >> 3));
+            const uint64_t nc = bgzf_deflate_device(s_.device, pipe.stream(), d_img, n, comp_.as<uint8_t>(), comp_.n, nullptr, false);
+            const uint64_t at = at_;
+            at_ += nc;
+            if (null) pipe.copy(comp_.as<uint8_t>(), nc, [](const uint8_t*, size_t, uint64_t) {}, true);
+            else pipe.copy(comp_.as<uint8_t>(), nc, [fd, fn, at](const uint8_t* p, size_t cnt, uint64_t off) { pwrite_all(fd, fn, p, cnt, at + off); }, false);
+            pipe.drain();            // comp_ is reused by the next piece
         } else {
-            stream_to_host(d_img, s.bytes[e], CH, [&](const uint8_t* buf, size_t n) {
-                const size_t n_blocks = (n + BGZF_IN - 1) / BGZF_IN;
+            const unsigned n_thr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+            pipe.copy(d_img, n, [&](const uint8_t* buf, size_t cnt, uint64_t) {
+                const size_t n_blocks = (cnt + BGZF_IN - 1) / BGZF_IN;
                 std::vector<std::vector<uint8_t>> parts(n_thr);
                 std::vector<std::string> errs(n_thr);
                 std::vector<std::thread> pool;
@@ -218,19 +298,76 @@ static void write_files(const jk_session& s) {
                     try {
                         const size_t b0 = n_blocks * t / n_thr, b1 = n_blocks * (t + 1) / n_thr;
                         for (size_t b = b0; b < b1; b++)
-                            bgzf_compress_block(buf + b * BGZF_IN, std::min(BGZF_IN, n - b * BGZF_IN), s.compress, parts[t]);
+                            bgzf_compress_block(buf + b * BGZF_IN, std::min(BGZF_IN, cnt - b * BGZF_IN), s_.compress, parts[t]);
                     } catch (const std::exception& ex) { errs[t] = ex.what(); }
                 });
                 for (std::thread& th : pool) th.join();
                 for (unsigned t = 0; t < n_thr; t++) {
                     if (!errs[t].empty()) throw Error(JK_ERR_IO, errs[t]);
-                    if (!parts[t].empty()) put(parts[t].data(), parts[t].size());
+                    if (!parts[t].empty()) { if (!null_) pwrite_all(fd_, fn_, parts[t].data(), parts[t].size(), at_); at_ += parts[t].size(); }
                 }
-            });
-            put(kBgzfEof, sizeof(kBgzfEof));
+            }, true);
         }
-        if (F.f) { FILE* f = F.f; F.f = nullptr; if (std::fclose(f) != 0) throw Error(JK_ERR_IO, "error closing " + fn); }
-        if (F.gz) { gzFile g = F.gz; F.gz = nullptr; if (gzclose(g) != Z_OK) throw Error(JK_ERR_IO, "error closing " + fn); }
+    }
+    // all pieces are in: end-of-file block (unless another part follows in the same file), close
+    void finish(HostPipe& pipe, bool with_eof = true) {
+        pipe.drain();
+        if (s_.compress > 0 && s_.bgzip && with_eof) { if (!null_) pwrite_all(fd_, fn_, kBgzfEof, sizeof(kBgzfEof), at_); at_ += sizeof(kBgzfEof); }
+        if (fd_ >= 0) { const int fd = fd_; fd_ = -1; if (::close(fd) != 0) throw Error(JK_ERR_IO, "error closing " + fn_); }
+        if (gz_) { gzFile g = gz_; gz_ = nullptr; if (gzclose(g) != Z_OK) throw Error(JK_ERR_IO, "error closing " + fn_); }
+    }
+    uint64_t bytes_written() const { return at_; }     // (gzip streams: not tracked)
+    uint64_t plain_bytes() const { return plain_; }
+    const std::string& name() const { return fn_; }
+    static void pwrite_all(int fd, const std::string& fn, const uint8_t* p, size_t n, uint64_t at) {
+        while (n) {
+            const ssize_t w = ::pwrite(fd, p, n, (off_t)at);
+            if (w < 0) { if (errno == EINTR) continue; throw Error(JK_ERR_IO, "write to " + fn + " failed: " + std::strerror(errno)); }
+            p += w; n -= (size_t)w; at += (uint64_t)w;
+        }
+    }
+private:
+    const jk_session& s_;
+    std::string fn_;
+    bool null_ = false;
+    int fd_ = -1; gzFile gz_ = nullptr;
+    uint64_t at_ = 0;            // next byte of the file
+    uint64_t plain_ = 0;         // FASTQ bytes taken so far
+    DevBuf comp_;
+};
+
+static const size_t PIPE_PIECE = BGZF_IN * 512;      // 33.4 MB pieces, a whole number of BGZF blocks
+inline int pipe_writers() {
+    if (const char* e = std::getenv("JK_WRITER_THREADS")) { const int v = std::atoi(e); if (v >= 0) return std::min(v, 16); }
+    return 4;
+}
+
+// A lane shard's image at its place in the shared file (see jk_session_write_shard).
+static void write_shard(const jk_session& s, const uint64_t* file_offset) {
+    if (!s.generated) throw Error(JK_ERR_ARG, "jk_session_write_shard before jk_session_generate");
+    if (s.compress > 0) throw Error(JK_ERR_UNSUPPORTED, "lane shards write uncompressed FASTQ only (compress the assembled file, or give each rank its own out_prefix)");
+    if (s.out_prefix.empty()) throw Error(JK_ERR_ARG, "out_prefix is empty");
+    HostPipe pipe(PIPE_PIECE, 6, pipe_writers());
+    for (uint32_t e = 0; e < s.n_ends; e++) {
+        FastqFile f(s, e, "", false, file_offset[e]);
+        f.add(pipe, s.d_out[e].as<uint8_t>(), s.bytes[e]);
+        f.finish(pipe);
+    }
+}
+
+// The resident image of a session into its files (jk_session_write).
+static void write_files(const jk_session& s) {
+    if (!s.generated) throw Error(JK_ERR_ARG, "jk_session_write before jk_session_generate");
+    if (s.streaming) throw Error(JK_ERR_ARG, "this session streams its output (stream_output): use jk_session_run");
+    if (s.n_shard != s.n_lanes_total)
+        throw Error(JK_ERR_UNSUPPORTED, "this session holds lanes " + std::to_string(s.lane_begin) + ".." + std::to_string(s.lane_end) + " of " +
+                    std::to_string(s.n_lanes_total) + ": writing it as the whole file would drop the other lanes' reads -- use "
+                    "jk_session_write_shard with the byte offsets from the ranks' jk_session_sizes");
+    HostPipe pipe(PIPE_PIECE, 6, pipe_writers());
+    for (uint32_t e = 0; e < s.n_ends; e++) {
+        FastqFile f(s, e);
+        f.add(pipe, s.d_out[e].as<uint8_t>(), s.bytes[e]);
+        f.finish(pipe);
     }
 }
 

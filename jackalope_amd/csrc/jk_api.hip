@@ -6,8 +6,10 @@
 //                api_illumina.h  api_pacbio.h   set-up of a run (the GPU counterpart of what write_reads_cpp_ /
 //                                               write_reads_one_filetype_ do before their parallel region,
 //                                               reference src/hts.h:323-500)
-//                api_launch.h                   one generate(): generator, scan, compaction on two streams
-//                api_sinks.h                    plain / gzip / BGZF sinks, BGZF on the device
+//                api_sinks.h                    plain / gzip / BGZF sinks, BGZF on the device; pinned copy-out pipe
+//                api_launch.h                   one pass over the batches: generator, scan, compaction on two streams;
+//                                               resident (generate) or streamed to the sinks (run)
+//                api_job.h                      a whole call: file sets (sep_files), devices, progress
 //                api_eval.h                     primitive evaluation hooks for the tests
 //   C ABI        this file (sessions, one-shot calls, BGZF, eval), api_builder.h (host helpers, mutation-table
 //                builder), api_genome.h (create_genome, read_fasta)
@@ -44,11 +46,36 @@
 #include "jk_session.h"
 #include "api_illumina.h"
 #include "api_pacbio.h"
-#include "api_launch.h"
 #include "api_sinks.h"
+#include "api_launch.h"
 #include "api_eval.h"
 
 using namespace jk;
+
+namespace jk {
+// PacBio pools and images are sized from the read-length model; a run that outgrows them is planned again, larger
+template <typename Run>
+static void with_replan(jk_session& s, Run run) {
+    s.retries = 0;
+    for (int attempt = 0;; attempt++) {
+        try { run(); return; }
+        catch (const Error& e) {
+            const bool again = (e.code == JK_ERR_RETRY || e.code == JK_ERR_RETRY_IMAGE) && attempt < 6 && s.replan;
+            if (!again) {
+                if (e.code == JK_ERR_RETRY) throw Error(JK_ERR_DEVICE, "PacBio pools overflowed even after growing them");
+                if (e.code == JK_ERR_RETRY_IMAGE) throw Error(JK_ERR_DEVICE, "the PacBio FASTQ image overflowed even after growing it");
+                throw;
+            }
+            if (e.code == JK_ERR_RETRY) s.pool_scale *= 2; else s.image_scale *= 2;
+            s.retries++;
+            s.replan();
+        }
+    }
+}
+static void generate_with_retry(jk_session& s) { with_replan(s, [&] { launch_generate(s); }); }
+static void stream_with_retry(jk_session& s, const std::string& suffix, bool with_eof) { with_replan(s, [&] { launch_stream(s, suffix, with_eof); }); }
+}  // namespace jk
+#include "api_job.h"
 
 extern "C" {
 
@@ -87,24 +114,6 @@ int jk_illumina_hap_open(const jk_hap_set* haps, const jk_illumina_args* args, j
     });
 }
 
-static void generate_with_retry(jk_session& s) {
-    s.retries = 0;
-    for (int attempt = 0;; attempt++) {
-        try { launch_generate(s); return; }
-        catch (const Error& e) {
-            const bool again = (e.code == JK_ERR_RETRY || e.code == JK_ERR_RETRY_IMAGE) && attempt < 6 && s.replan;
-            if (!again) {
-                if (e.code == JK_ERR_RETRY) throw Error(JK_ERR_DEVICE, "PacBio pools overflowed even after growing them");
-                if (e.code == JK_ERR_RETRY_IMAGE) throw Error(JK_ERR_DEVICE, "the PacBio FASTQ image overflowed even after growing it");
-                throw;
-            }
-            if (e.code == JK_ERR_RETRY) s.pool_scale *= 2; else s.image_scale *= 2;
-            s.retries++;
-            s.replan();
-        }
-    }
-}
-
 static std::vector<double> pb_hap_probs_of(const jk_hap_set& hs, const jk_pacbio_args& a) {
     if (!a.haplotype_probs) return std::vector<double>(hs.n_haps, 1.0);
     return std::vector<double>(a.haplotype_probs, a.haplotype_probs + hs.n_haps);
@@ -132,50 +141,13 @@ int jk_pacbio_hap_open(const jk_hap_set* haps, const jk_pacbio_args* args, jk_se
     });
 }
 
-int jk_pacbio_ref(const jk_ref_genome* genome, const jk_pacbio_args* args) {
-    jk_session* s = nullptr;
-    int rc = jk_pacbio_ref_open(genome, args, &s);
-    if (rc == JK_OK) rc = jk_session_generate(s);
-    if (rc == JK_OK) rc = jk_session_write(s);
-    std::string keep = g_last_error;
-    jk_session_close(s);
-    g_last_error = keep;
-    return rc;
-}
-
-int jk_pacbio_hap(const jk_hap_set* haps, const jk_pacbio_args* args) {
-    return guarded([&] {
-        if (!haps || !args) throw Error(JK_ERR_ARG, "NULL argument");
-        SeedReader seeds{args->seeds};
-        const std::vector<double> probs = pb_hap_probs_of(*haps, *args);
-        if (!args->sep_files) {
-            std::unique_ptr<jk_session> s(new jk_session());
-            open_pacbio_hap(*s, *haps, *args, probs, args->n_reads, seeds);
-            generate_with_retry(*s);
-            write_files(*s);
-            return;
-        }
-        std::vector<uint64_t> per_file = reads_per_group(args->n_reads, probs, seeds);   // src/hts.h:526-529, one read end
-        for (uint64_t h = 0; h < haps->n_haps; h++) {
-            if (args->abort_flag && *args->abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
-            std::vector<double> one_hot(haps->n_haps, 0.0);
-            one_hot[h] = 1;
-            std::unique_ptr<jk_session> s(new jk_session());
-            open_pacbio_hap(*s, *haps, *args, one_hot, per_file[h], seeds);
-            s->out_prefix += std::string("_") + (haps->hap_names ? haps->hap_names[h] : "");
-            generate_with_retry(*s);
-            write_files(*s);
-        }
-    });
-}
-
 int jk_session_generate(jk_session* s) {
     return guarded([&] { if (!s) throw Error(JK_ERR_ARG, "NULL session"); generate_with_retry(*s); });
 }
 
 int jk_session_sizes(const jk_session* s, uint64_t bytes[2], uint64_t* reads, uint32_t* n_ends) {
     return guarded([&] {
-        if (!s || !s->generated) throw Error(JK_ERR_ARG, "session has not generated yet");
+        if (!s || !(s->generated || s->streamed)) throw Error(JK_ERR_ARG, "session has not generated yet");
         if (bytes) { bytes[0] = s->bytes[0]; bytes[1] = s->bytes[1]; }
         if (reads) *reads = s->reads_made;
         if (n_ends) *n_ends = s->n_ends;
@@ -230,7 +202,7 @@ int jk_session_write(const jk_session* s) {
 
 int jk_session_timing(const jk_session* s, double ms[3]) {
     return guarded([&] {
-        if (!s || !s->generated) throw Error(JK_ERR_ARG, "session has not generated yet");
+        if (!s || !(s->generated || s->streamed)) throw Error(JK_ERR_ARG, "session has not generated yet");
         ms[0] = s->ms[0]; ms[1] = s->ms[1]; ms[2] = s->ms[2];
     });
 }
@@ -253,44 +225,74 @@ void jk_session_close(jk_session* s) {
     delete s;
 }
 
-int jk_illumina_ref(const jk_ref_genome* genome, const jk_illumina_args* args) {
-    jk_session* s = nullptr;
-    int rc = jk_illumina_ref_open(genome, args, &s);
-    if (rc == JK_OK) rc = jk_session_generate(s);
-    if (rc == JK_OK) rc = jk_session_write(s);
-    std::string keep = g_last_error;
-    jk_session_close(s);
+// ---- jobs and the one-shot entry points ------------------------------------------------------------------------
+static int make_job(jk_job::Kind kind, const jk_ref_genome* genome, const jk_hap_set* haps, const jk_illumina_args* ia,
+                    const jk_pacbio_args* pa, jk_job** out) {
+    return guarded([&] {
+        if ((!genome && !haps) || (!ia && !pa) || !out) throw Error(JK_ERR_ARG, "NULL argument");
+        std::unique_ptr<jk_job> j(new jk_job());
+        j->kind = kind; j->genome = genome; j->haps = haps;
+        if (ia) { j->ia = *ia; j->seeds = SeedReader{ia->seeds}; job_common_init(*j, ia->n_threads, ia->devices, ia->n_devices, ia->device, ia->sep_files); }
+        else { j->pa = *pa; j->seeds = SeedReader{pa->seeds}; job_common_init(*j, pa->n_threads, pa->devices, pa->n_devices, pa->device, pa->sep_files); }
+        if ((ia && (ia->lane_begin || ia->lane_end)) || (pa && (pa->lane_begin || pa->lane_end)))
+            throw Error(JK_ERR_ARG, "lane shards belong to the session API; a job (and a one-shot call) covers all lanes, over `devices`");
+        job_start(*j);
+        *out = j.release();
+    });
+}
+int jk_illumina_ref_job(const jk_ref_genome* genome, const jk_illumina_args* args, jk_job** out) { return make_job(jk_job::ILL_REF, genome, nullptr, args, nullptr, out); }
+int jk_illumina_hap_job(const jk_hap_set* haps, const jk_illumina_args* args, jk_job** out) { return make_job(jk_job::ILL_HAP, nullptr, haps, args, nullptr, out); }
+int jk_pacbio_ref_job(const jk_ref_genome* genome, const jk_pacbio_args* args, jk_job** out) { return make_job(jk_job::PB_REF, genome, nullptr, nullptr, args, out); }
+int jk_pacbio_hap_job(const jk_hap_set* haps, const jk_pacbio_args* args, jk_job** out) { return make_job(jk_job::PB_HAP, nullptr, haps, nullptr, args, out); }
+uint32_t jk_job_n_files(const jk_job* j) { return j ? j->n_files : 0; }
+int jk_job_plan_next(jk_job* j) { return guarded([&] { if (!j) throw Error(JK_ERR_ARG, "NULL job"); job_plan_next(*j); }); }
+int jk_job_run(jk_job* j) { return guarded([&] { if (!j) throw Error(JK_ERR_ARG, "NULL job"); job_run(*j); }); }
+int jk_job_progress(const jk_job* j, uint64_t* reads_done, uint64_t* reads_total) {
+    return guarded([&] {
+        if (!j) throw Error(JK_ERR_ARG, "NULL job");
+        std::lock_guard<std::mutex> l(j->m);
+        uint64_t d = j->done_before.load();
+        for (const jk_session* s : j->live) d += s->progress_done.load();
+        if (reads_done) *reads_done = d;
+        if (reads_total) *reads_total = j->total_reads;
+    });
+}
+uint64_t jk_job_seed_words_used(const jk_job* j) { return j ? j->seeds.pos : 0; }
+void jk_job_free(jk_job* j) { delete j; }
+
+static int one_shot(jk_job::Kind kind, const jk_ref_genome* genome, const jk_hap_set* haps, const jk_illumina_args* ia, const jk_pacbio_args* pa) {
+    jk_job* j = nullptr;
+    int rc = make_job(kind, genome, haps, ia, pa, &j);
+    for (uint32_t f = 0; rc == JK_OK && f < j->n_files; f++) {
+        const volatile int32_t* af = ia ? ia->abort_flag : pa->abort_flag;
+        if (af && *af) { g_last_error = "aborted"; rc = JK_ERR_ABORTED; break; }
+        rc = jk_job_plan_next(j);
+        if (rc == JK_OK) rc = jk_job_run(j);
+    }
+    const std::string keep = g_last_error;
+    jk_job_free(j);
     g_last_error = keep;
     return rc;
 }
+int jk_illumina_ref(const jk_ref_genome* genome, const jk_illumina_args* args) { return one_shot(jk_job::ILL_REF, genome, nullptr, args, nullptr); }
+int jk_illumina_hap(const jk_hap_set* haps, const jk_illumina_args* args) { return one_shot(jk_job::ILL_HAP, nullptr, haps, args, nullptr); }
+int jk_pacbio_ref(const jk_ref_genome* genome, const jk_pacbio_args* args) { return one_shot(jk_job::PB_REF, genome, nullptr, nullptr, args); }
+int jk_pacbio_hap(const jk_hap_set* haps, const jk_pacbio_args* args) { return one_shot(jk_job::PB_HAP, nullptr, haps, nullptr, args); }
 
-int jk_illumina_hap(const jk_hap_set* haps, const jk_illumina_args* args) {
+int jk_session_run(jk_session* s) {
     return guarded([&] {
-        if (!haps || !args) throw Error(JK_ERR_ARG, "NULL argument");
-        SeedReader seeds{args->seeds};
-        const std::vector<double> probs = hap_probs_of(*haps, *args);
-        if (!args->sep_files) {
-            std::unique_ptr<jk_session> s(new jk_session());
-            open_illumina_hap(*s, *haps, *args, probs, args->n_reads, seeds);
-            launch_generate(*s);
-            write_files(*s);
-            return;
-        }
-        // write_reads_cpp_sep_files_ (src/hts.h:512-552): reads per file, then one run per haplotype with
-        // one-hot haplotype probabilities and prefix <out_prefix>_<haplotype>
-        const uint64_t n_ends = args->paired ? 2 : 1;
-        std::vector<uint64_t> per_file = reads_per_group(args->n_reads / n_ends, probs, seeds);
-        for (uint64_t& v : per_file) v *= n_ends;
-        for (uint64_t h = 0; h < haps->n_haps; h++) {
-            if (args->abort_flag && *args->abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
-            std::vector<double> one_hot(haps->n_haps, 0.0);
-            one_hot[h] = 1;
-            std::unique_ptr<jk_session> s(new jk_session());
-            open_illumina_hap(*s, *haps, *args, one_hot, per_file[h], seeds);
-            s->out_prefix += std::string("_") + (haps->hap_names ? haps->hap_names[h] : "");
-            launch_generate(*s);
-            write_files(*s);
-        }
+        if (!s) throw Error(JK_ERR_ARG, "NULL session");
+        if (s->n_shard != s->n_lanes_total)
+            throw Error(JK_ERR_UNSUPPORTED, "a lane shard cannot stream into the run's files: its place in them depends on the other shards "
+                        "(generate resident and use jk_session_write_shard, or run the whole call as a job over `devices`)");
+        stream_with_retry(*s, "", true);
+    });
+}
+int jk_session_progress(const jk_session* s, uint64_t* reads_done, uint64_t* reads_total) {
+    return guarded([&] {
+        if (!s) throw Error(JK_ERR_ARG, "NULL session");
+        if (reads_done) *reads_done = s->progress_done.load();
+        if (reads_total) *reads_total = s->progress_total;
     });
 }
 

@@ -50,6 +50,7 @@ struct Batch {
     uint64_t lane0;        // first lane (relative to the shard)
     uint32_t n_lanes;
     uint64_t pool_bytes;   // per read end
+    uint64_t n_reads;      // planned reads of its lanes (progress reporting)
 };
 
 template <typename F>

@@ -95,6 +95,18 @@ struct LanePlan {
     uint64_t shard_begin_word = 0, shard_end_word = 0;   // add_n_reads words of this shard's lanes: [begin, end) in the stream
 };
 
+// Lanes [begin, end) of a plan made for lanes [0, T): what one device of a multi-device run takes.
+inline LanePlan slice_plan(const LanePlan& full, uint64_t T, uint64_t begin, uint64_t end) {
+    LanePlan P;
+    const uint64_t n = end - begin, n_cells = T ? full.quotas.size() / T : 0;
+    P.lane_seeds.assign(full.lane_seeds.begin() + begin * 8, full.lane_seeds.begin() + end * 8);
+    P.lane_reads.assign(full.lane_reads.begin() + begin, full.lane_reads.begin() + end);
+    P.quotas.assign_zero((size_t)n_cells * n);
+    for (uint64_t c = 0; c < n_cells; c++) std::memcpy(P.quotas.data() + c * n, full.quotas.data() + c * T + begin, n * 4);
+    P.words_used = full.words_used; P.shard_begin_word = full.shard_begin_word; P.shard_end_word = full.shard_end_word;
+    return P;
+}
+
 namespace plan_detail {
 
 // words a lane takes after its hap-level split (`hr` = reads per haplotype): one chromosome split per haplotype

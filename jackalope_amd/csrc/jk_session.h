@@ -1,6 +1,7 @@
 // jk_session.h -- state of one sequencing run (what jk_*_open returns)
 // (part of the one translation unit jk_api.hip; see the include list there)
 #pragma once
+#include <atomic>
 
 
 #ifndef JK_ILL_BLOCK
@@ -49,6 +50,11 @@ struct jk_session {
     std::vector<Batch> batches;
     std::vector<uint64_t> batch_pool_off_index;   // index into d_pool_off of each batch's first entry
     int n_pool_sets = 2;              // pool sets in rotation (3 when memory allows: see plan_pools_common)
+    DevBuf d_img[2][2] /* streaming: [slot][end] one batch's compacted image */, d_zero;
+    uint64_t img_cap = 0;
+    std::atomic<uint64_t> progress_done{0};       // reads whose FASTQ has left the device (streaming) / been generated
+    uint64_t progress_total = 0;
+    bool streamed = false;                        // a streaming run has completed
     DevBuf d_pool[3][2] /* [set][end] */, d_out[2], d_lane_bytes[2], d_lane_off[2], d_block_sums, d_base[2], d_lane_made, d_evw, d_err, d_result;
     uint64_t out_cap = 0;
     IlluminaKernelParams kp{};                    // template, per-batch fields filled at launch

@@ -82,6 +82,45 @@ def _check_file_existence(fns, compress, overwrite):
         raise FileExistsError("\nOne or more of the output files already exists, and argument `overwrite` is FALSE.")
 
 
+class Job:
+    """A whole illumina()/pacbio() call in two steps per output file set (jk_job_*): plan_next() reads the seed words
+    on the calling thread, run() generates and writes on any thread while progress() may be polled from another."""
+
+    def __init__(self, handle, keep):
+        self._h = handle
+        self._keep = keep
+
+    def n_files(self):
+        return int(_abi.lib().jk_job_n_files(self._h))
+
+    def plan_next(self):
+        _abi.check(_abi.lib().jk_job_plan_next(self._h))
+
+    def run(self):
+        rc = _abi.lib().jk_job_run(self._h)          # (called on worker threads too: the error text is thread-local there)
+        if rc != _abi.JK_OK:
+            raise _abi.JackalopeHipError(rc, _abi.lib().jk_last_error().decode("utf-8", "replace"))
+
+    def progress(self):
+        d, t = C.c_uint64(), C.c_uint64()
+        _abi.check(_abi.lib().jk_job_progress(self._h, C.byref(d), C.byref(t)))
+        return int(d.value), int(t.value)
+
+    def seed_words_used(self):
+        return int(_abi.lib().jk_job_seed_words_used(self._h))
+
+    def close(self):
+        if self._h:
+            _abi.lib().jk_job_free(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 class IlluminaSession:
     """Generated FASTQ held in HBM (jk_session_*): open -> generate -> fetch / write."""
 
@@ -92,6 +131,16 @@ class IlluminaSession:
     def generate(self):
         _abi.check(_abi.lib().jk_session_generate(self._h))
         return self
+
+    def run(self):
+        """Streaming sessions (stream_output=True): generate and write the files (or the null sink) in one pass."""
+        _abi.check(_abi.lib().jk_session_run(self._h))
+        return self
+
+    def progress(self):
+        d, t = C.c_uint64(), C.c_uint64()
+        _abi.check(_abi.lib().jk_session_progress(self._h, C.byref(d), C.byref(t)))
+        return int(d.value), int(t.value)
 
     def sizes(self):
         b = (C.c_uint64 * 2)()
@@ -170,7 +219,7 @@ def make_args(out_prefix, n_reads, paired, matepair, prof1, prof2, ins_prob1, de
               frag_len_shape, frag_len_scale, frag_len_min, frag_len_max, barcodes, prob_dup, n_threads,
               read_pool_size, words, compress=0, comp_method="bgzip", sep_files=False, haplotype_probs=None,
               lane_begin=0, lane_end=0, device=0, max_batch_bytes=0, seed_fn=None, abort_flag=None, seed_offset_words=None,
-              devices=None):
+              devices=None, stream_output=False):
     """Assemble jk_illumina_args; returns (struct, keep-alive list)."""
     a = _abi.IlluminaArgs()
     keep = []
@@ -232,6 +281,7 @@ def make_args(out_prefix, n_reads, paired, matepair, prof1, prof2, ins_prob1, de
         dv = np.ascontiguousarray(devices, dtype=np.int32)
         keep.append(dv)
         a.devices, a.n_devices = dv.ctypes.data_as(C.POINTER(C.c_int32)), dv.size
+    a.stream_output = int(bool(stream_output))
     return a, keep
 
 
@@ -241,7 +291,7 @@ def illumina(obj, out_prefix, n_reads, read_length, paired, frag_mean=400, frag_
              barcodes=None, prob_dup=0.02, sep_files=False, compress=False, comp_method="bgzip", n_threads=1,
              read_pool_size=1000, show_progress=False, overwrite=False,
              seed=None, seed_words=None, device=0, lane_begin=0, lane_end=0, max_batch_bytes=0, _session=False,
-             seed_fn=None, abort_flag=None, seed_offset_words=None, devices=None):
+             seed_fn=None, abort_flag=None, seed_offset_words=None, devices=None, stream_output=False, _job=False):
     """Create and write Illumina reads (R/hts_illumina.R:593-732).
 
     With ``_session=True`` nothing is written: the opened `IlluminaSession` is returned instead
@@ -257,7 +307,7 @@ def illumina(obj, out_prefix, n_reads, read_length, paired, frag_mean=400, frag_
     if is_ref:
         sep_files = False
     ends = 2 if paired else 1
-    if not _session:
+    if not _session and out_prefix:
         if not sep_files:
             fns = ["%s_R%d.fq" % (out_prefix, i + 1) for i in range(ends)]
         else:
@@ -296,8 +346,14 @@ def illumina(obj, out_prefix, n_reads, read_length, paired, frag_mean=400, frag_
     args, keep = make_args(out_prefix, n_reads, paired, matepair, prof1, prof2, ins_prob1, del_prob1, ins_prob2,
                            del_prob2, frag_len_shape, frag_len_scale, frag_len_min, frag_len_max, barcodes, prob_dup,
                            n_threads, read_pool_size, seed_words, compress, comp_method, sep_files, haplotype_probs,
-                           lane_begin, lane_end, device, max_batch_bytes, seed_fn, abort_flag, seed_offset_words, devices)
+                           lane_begin, lane_end, device, max_batch_bytes, seed_fn, abort_flag, seed_offset_words, devices,
+                           stream_output)
     L = _abi.lib()
+    if _job:
+        view, keep2 = obj._view()
+        h = C.c_void_p()
+        _abi.check((L.jk_illumina_ref_job if is_ref else L.jk_illumina_hap_job)(C.byref(view), C.byref(args), C.byref(h)))
+        return Job(h, [keep, keep2, view, args])
     if is_ref:
         view, keep2 = obj._view()
         if _session:

@@ -63,7 +63,7 @@ def pacbio(obj, out_prefix, n_reads,
            prob_dup=0.0, haplotype_probs=None, sep_files=False, compress=False, comp_method="bgzip", n_threads=1,
            read_pool_size=100, show_progress=False, overwrite=False,
            seed=None, seed_words=None, device=0, lane_begin=0, lane_end=0, max_batch_bytes=0, _session=False,
-           seed_offset_words=None, devices=None):
+           seed_offset_words=None, devices=None, stream_output=False, _job=False, abort_flag=None):
     """Create and write PacBio reads (R/hts_pacbio.R:232-348).  ``_session=True`` returns the opened
     session (FASTQ stays in HBM) instead of writing ``<out_prefix>_R1.fq``."""
     check_pacbio_args(obj, n_reads, haplotype_probs, sep_files, compress, comp_method, n_threads, read_pool_size,
@@ -73,7 +73,7 @@ def pacbio(obj, out_prefix, n_reads,
     is_ref = isinstance(obj, RefGenome)
     if is_ref:
         sep_files = False
-    if not _session:
+    if not _session and out_prefix:
         fns = ["%s_R1.fq" % out_prefix] if not sep_files else ["%s_%s_R1.fq" % (out_prefix, h) for h in obj.hap_names()]
         _check_file_existence(fns, bool(compress), overwrite)
     if isinstance(compress, (bool, np.bool_)):
@@ -126,8 +126,17 @@ def pacbio(obj, out_prefix, n_reads,
         dv = np.ascontiguousarray(devices, dtype=np.int32)
         keep.append(dv)
         a.devices, a.n_devices = dv.ctypes.data_as(C.POINTER(C.c_int32)), dv.size
+    a.stream_output = int(bool(stream_output))
+    if abort_flag is not None:
+        keep.append(abort_flag)
+        a.abort_flag = abort_flag.ctypes.data_as(C.POINTER(C.c_int32))
     L = _abi.lib()
     view, keep2 = obj._view()
+    if _job:
+        from .illumina import Job
+        h = C.c_void_p()
+        _abi.check((L.jk_pacbio_ref_job if is_ref else L.jk_pacbio_hap_job)(C.byref(view), C.byref(a), C.byref(h)))
+        return Job(h, [keep, keep2, view, a])
     if _session:
         h = C.c_void_p()
         fn = L.jk_pacbio_ref_open if is_ref else L.jk_pacbio_hap_open

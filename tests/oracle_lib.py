@@ -108,7 +108,7 @@ def alias_build(probs):
 
 
 def _take(ptr, n):
-    data = C.string_at(ptr, n) if n else b""
+    data = bytes((C.c_char * n).from_address(ptr.value)) if n else b""     # (string_at takes an int size: 2 GiB limit)
     lib().orc_free(ptr)
     return data
 

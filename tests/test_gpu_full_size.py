@@ -292,7 +292,7 @@ def test_pacbio_image_guard(ja, O):
     image.  The compaction must notice before writing past it (JK_KERR_IMAGE_FULL): with re-planning disabled the run
     ends with an error, otherwise it re-plans with a larger image and the result equals the oracle."""
     ref = ja.synthetic_genome([3_000_000, 2_000_000], seed=8)
-    n_reads, T = 120_000, 4096
+    n_reads, T = 40_000, 2048
     words = ja.seed_words(11, 16 * T)
     # nominal log-normal mean ~ 8.2 kb; a read below 9 kb is redrawn (up to 10 times), so the realised mean is that of
     # the distribution's upper 38 %, ~12 kb: a third above the 9 kb the image is sized for (+ 12.5 % + 64 MB)
