@@ -106,13 +106,27 @@ static void job_plan_next(jk_job& j) {
 static void append_file(const std::string& dst, const std::string& src) {
     struct Fd { int fd = -1; ~Fd() { if (fd >= 0) ::close(fd); } } in, out;
     in.fd = ::open(src.c_str(), O_RDONLY);
-    out.fd = ::open(dst.c_str(), O_WRONLY | O_APPEND);
+    out.fd = ::open(dst.c_str(), O_WRONLY);       // (sendfile refuses O_APPEND descriptors: seek to the end instead)
     if (in.fd < 0 || out.fd < 0) throw Error(JK_ERR_IO, "Unable to open file " + (in.fd < 0 ? src : dst) + ".\n");
     struct stat st;
-    if (::fstat(in.fd, &st) != 0) throw Error(JK_ERR_IO, "stat of " + src + " failed");
+    if (::fstat(in.fd, &st) != 0 || ::lseek(out.fd, 0, SEEK_END) < 0) throw Error(JK_ERR_IO, "stat of " + src + " / seek in " + dst + " failed");
     off_t left = st.st_size;
+    bool use_sendfile = true;
+    std::vector<char> buf;
     while (left > 0) {
-        const ssize_t n = ::sendfile(out.fd, in.fd, nullptr, (size_t)std::min<off_t>(left, (off_t)1 << 30));
+        ssize_t n;
+        if (use_sendfile) {
+            n = ::sendfile(out.fd, in.fd, nullptr, (size_t)std::min<off_t>(left, (off_t)1 << 30));
+            if (n < 0 && (errno == EINVAL || errno == ENOSYS)) { use_sendfile = false; continue; }    // file system without it: copy through a buffer
+        } else {
+            if (buf.empty()) buf.resize(8u << 20);
+            n = ::read(in.fd, buf.data(), (size_t)std::min<off_t>(left, (off_t)buf.size()));
+            for (ssize_t done = 0; n > 0 && done < n;) {
+                const ssize_t w = ::write(out.fd, buf.data() + done, (size_t)(n - done));
+                if (w < 0) { if (errno == EINTR) continue; n = -1; break; }
+                done += w;
+            }
+        }
         if (n < 0) { if (errno == EINTR) continue; throw Error(JK_ERR_IO, "appending " + src + " to " + dst + " failed: " + std::strerror(errno)); }
         if (n == 0) break;
         left -= n;
