@@ -190,6 +190,7 @@ typedef struct jk_pacbio_args {
 
 const char* jk_last_error(void);
 const char* jk_version(void);
+int jk_device_count(void);                /* MI355X devices visible to this process (0 when there is none) */
 
 /* One-shot entry points: generate and write the FASTQ files, like the reference's functions. */
 int jk_illumina_ref(const jk_ref_genome* genome, const jk_illumina_args* args);

@@ -80,7 +80,8 @@ static void stream_with_retry(jk_session& s, const std::string& suffix, bool wit
 extern "C" {
 
 const char* jk_last_error(void) { return g_last_error.c_str(); }
-const char* jk_version(void) { return "jackalope_hip 0.1 (gfx950)"; }
+const char* jk_version(void) { return "jackalope_hip 0.2 (gfx950)"; }
+int jk_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
 #ifdef JK_TIMELINE
 int jk_debug_timeline(uint64_t* out, uint64_t n_words) {     // experiment builds only
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(jk::g_timeline), n_words * 8) == hipSuccess ? 0 : 1;
