@@ -62,66 +62,6 @@ def pmc_traffic(pairs_per_launch):
         return None
 
 
-def pacbio_main(a):
-    """Secondary line: PacBio reads (uniform 5-15 kb custom lengths, mean 10 kb) at 20x of a synthetic genome:
-    BASELINE configs[4] at full size (3 Gbp, 6 M reads, 120 GB of FASTQ kept in HBM) unless --genome-mbp says otherwise.
-    Same timing contract."""
-    import torch
-    import jackalope_amd as ja
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        raise SystemExit("the PacBio line is single-GPU in this round")
-    torch.cuda.set_device(local_rank)
-    mbp = a.genome_mbp if a.genome_mbp != 100.0 else 3000.0
-    genome = ja.synthetic_genome([int(mbp * 1e6)], seed=3)
-    n_reads = int(mbp * 1e6 * 20 / 10000)
-    lanes = a.lanes
-    lens = list(range(5000, 15001, 500))
-    words = ja.seed_words(12345, 16 * lanes)
-    sess = ja.pacbio(genome, None, n_reads, n_threads=lanes, seed_words=words, custom_read_lengths=lens, device=local_rank,
-                     _session=True)
-    for _ in range(a.warmup):
-        sess.generate()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    gen_ms = 0.0
-    for _ in range(a.steps):
-        sess.generate()
-        gen_ms += sess.timing_ms()["generate_kernel"]
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    sizes, reads = sess.sizes()
-    n_launch = max(sess.n_batches(), 1)
-    alg = (sizes[0] + sizes[0] // 2) / n_launch                  # FASTQ bytes (~2 per base) + 1 reference byte per base
-    kern_s = gen_ms / a.steps / 1e3 / n_launch
-    out = {"metric": "M PacBio reads/sec (mean 10 kb, 20x)", "value": round(reads * a.steps / elapsed / 1e6, 3),
-           "unit": "M reads/sec", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-           "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-           "config": {"workload": "configs[4]: %g Mbp synthetic ref, PacBio defaults, custom read lengths uniform "
-                                  "5-15 kb (mean 10 kb), 20x" % mbp, "reads_per_gpu": n_reads, "lanes_per_gpu": lanes},
-           "gbases_per_sec": round(sizes[0] / 2 * a.steps / elapsed / 1e9, 2),
-           "roofline": {"bound": "hbm", "achieved": round(alg / kern_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(alg / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "pacbio_kernel<ref>",
-                        "launches_per_step": n_launch, "kernel_ms": round(kern_s * 1e3, 3)}}
-    if not a.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O
-        cores = min(os.cpu_count() or 1, 64)
-        O.lib().orc_set_threads(cores)
-        cl = cores * 4
-        sample = 3000 * cl
-        t1 = time.perf_counter()
-        O.pacbio_ref(genome, {"custom_read_lengths": lens}, n_reads=sample, n_threads=cl, words=ja.seed_words(1, 16 * cl), discard=True)
-        dt = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": round(sample / dt / 1e6, 6), "unit": "M reads/sec", "cores": cores, "kind": "port",
-                               "sample": "%d reads of the same workload on %d lanes, oracle with OpenMP, null sink (%.1f s)" % (sample, cl, dt)}
-    print(json.dumps(out))
-    sess.close()
-
-
 def bgzf_main(a):
     """Secondary line: the compressed sink.  The R1 FASTQ image of the headline workload (configs[1], 10 M pairs,
     3.3 GB) is BGZF-compressed where it lies in HBM (jk_bgzf_deflate).  A step = one pass over that image."""
@@ -314,6 +254,191 @@ def read_fasta_main(a):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def dist_setup(a):
+    """One process per GPU: rank/world from the launcher's environment, RCCL (backend "nccl") for the count exchange."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % a.gpus)
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or os.environ.get("JK_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    return rank, local_rank, world, use_dist
+
+
+def timed_steps(a, sess, use_dist):
+    """W warm-up passes, then K passes between barrier + synchronize on both sides; MAX over ranks of the elapsed time."""
+    import torch
+    import torch.distributed as dist
+
+    def sync():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        sess.generate()
+    sync()
+    t0 = time.perf_counter()
+    gen_ms = all_ms = 0.0
+    for _ in range(a.steps):
+        sess.generate()                      # blocks until the step's stream work is done
+        tm = sess.timing_ms()                # HIP events on the stream the kernels run on
+        gen_ms += tm["generate_kernel"]
+        all_ms += tm["total"]
+    sync()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if use_dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item()), gen_ms, all_ms
+
+
+def measured_copy_gbs():
+    """The second HBM denominator: bytes read + written per second by a plain device-to-device
+    copy of 2 GiB on this box."""
+    import torch
+    n = 2 << 30
+    src = torch.empty(n, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(n, dtype=torch.uint8, device="cuda")
+    src.fill_(7)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 10 / (e0.elapsed_time(e1) / 1e3) / 1e9
+
+
+def d2h_inclusive(open_stream, steps, compress):
+    """Whole-job rate with the FASTQ (or its device-made BGZF form) copied to host memory as it is generated: a
+    streaming session with a null sink (pinned double-buffered D2H overlapped with the next launch; nothing is written)."""
+    s = open_stream(compress)
+    with s:
+        s.run()                                  # warm-up: pinned buffers, BGZF tables
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s.run()
+        dt = time.perf_counter() - t0
+        _, reads = s.sizes()
+    return reads * steps / dt
+
+
+def pacbio_main(a):
+    """Secondary line: PacBio reads (uniform 5-15 kb custom lengths, mean 10 kb) at 20x of a synthetic genome:
+    BASELINE configs[4] at full size per GPU (3 Gbp, 6 M reads, 120 GB of FASTQ kept in HBM) unless --genome-mbp says
+    otherwise; N GPUs take N such jobs' lanes (weak scaling), lane blocks via the seed-offset exchange."""
+    rank, local_rank, world, use_dist = dist_setup(a)
+    import torch
+    import torch.distributed as dist
+    import jackalope_amd as ja
+    from jackalope_amd.sharding import open_shard, exchange_counts
+    mbp = a.genome_mbp if a.genome_mbp != 100.0 else 3000.0
+    genome = ja.synthetic_genome([int(mbp * 1e6)], seed=3)
+    n_reads = int(mbp * 1e6 * 20 / 10000) * world
+    lanes = a.lanes * world
+    lens = list(range(5000, 15001, 500))
+    words = ja.seed_words(12345, 16 * lanes)
+    sess = open_shard(lambda lo, hi, off: ja.pacbio(genome, None, n_reads, n_threads=lanes, seed_words=words, custom_read_lengths=lens,
+                                                    device=local_rank, lane_begin=lo, lane_end=hi, seed_offset_words=off, _session=True),
+                      lanes, n_reads, 8, device="cuda" if use_dist else None)
+    elapsed, gen_ms, all_ms = timed_steps(a, sess, use_dist)
+    sizes, reads = sess.sizes()
+    offsets, (total_reads, total_bytes) = exchange_counts(reads, sizes, device="cuda")
+    if rank == 0:
+        n_launch = max(sess.n_batches(), 1)
+        alg = (sizes[0] + sizes[0] // 2) / n_launch                  # FASTQ bytes (~2 per base) + 1 reference byte per base
+        kern_s = gen_ms / a.steps / 1e3 / n_launch
+        out = {"metric": "M PacBio reads/sec (mean 10 kb, 20x)", "value": round(total_reads * a.steps / elapsed / 1e6, 3),
+               "unit": "M reads/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": "configs[4]: %g Mbp synthetic ref, PacBio defaults, custom read lengths uniform "
+                                      "5-15 kb (mean 10 kb), 20x per GPU" % mbp, "reads_per_gpu": n_reads // world, "lanes_per_gpu": a.lanes,
+                          "parallelism": "lanes sharded over %d GPU(s), no data-path collective" % world},
+               "gbases_per_sec": round(total_bytes[0] / 2 * a.steps / elapsed / 1e9, 2),
+               "roofline": {"bound": "hbm", "achieved": round(alg / kern_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(alg / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "pacbio_kernel<ref>",
+                            "launches_per_step": n_launch, "kernel_ms": round(kern_s * 1e3, 3)}}
+        if not a.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            cores = min(os.cpu_count() or 1, 64)
+            O.lib().orc_set_threads(cores)
+            cl = cores * 4
+            sample = 3000 * cl
+            t1 = time.perf_counter()
+            O.pacbio_ref(genome, {"custom_read_lengths": lens}, n_reads=sample, n_threads=cl, words=ja.seed_words(1, 16 * cl), discard=True)
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(sample / dt / 1e6, 6), "unit": "M reads/sec", "cores": cores, "kind": "port",
+                                   "sample": "%d reads of the same workload on %d lanes, oracle with OpenMP, null sink (%.1f s)" % (sample, cl, dt)}
+        print(json.dumps(out))
+    sess.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def hap_main(a):
+    """Secondary line: BASELINE configs[3]'s share of one GPU -- 3 Gbp (24 x 125 Mbp, made on the device), 8 haplotypes
+    (28.7 M mutations), 37.5 M PE150 pairs per GPU on --lanes lanes; N GPUs take N shares (at N = 8: the whole
+    configs[3] job), lane blocks via the seed-offset exchange (RCCL all-gather of two integers per rank)."""
+    rank, local_rank, world, use_dist = dist_setup(a)
+    import torch
+    import torch.distributed as dist
+    import jackalope_amd as ja
+    from jackalope_amd.genome import random_haplotypes_flat
+    from jackalope_amd.sharding import open_shard, exchange_counts
+    n_chroms, chrom_len, n_haps = 24, int(125e6 * (a.genome_mbp / 100.0 if a.genome_mbp != 100.0 else 1.0)), 8
+    dev = ja.create_genome(n_chroms, chrom_len, 0, seed_words=ja.seed_words(3, 8), device=local_rank)
+    ref = ja.RefGenome([dev.chrom(i) for i in range(n_chroms)], names=dev.names)
+    dev.close()
+    hs = random_haplotypes_flat(ref, n_haps, seed=31)
+    pairs_per_gpu = n_chroms * chrom_len * 30 // 300 // 8
+    lanes_per_gpu = a.lanes if a.lanes != (1 << 20) else (1 << 18)
+    lanes, n_reads = lanes_per_gpu * world, 2 * pairs_per_gpu * world
+    words = ja.seed_words(12345, hs.seed_budget(lanes))
+    t0 = time.perf_counter()
+    sess = open_shard(lambda lo, hi, off: ja.illumina(hs, None, n_reads, 150, True, n_threads=lanes, seed_words=words, device=local_rank,
+                                                      lane_begin=lo, lane_end=hi, seed_offset_words=off, _session=True),
+                      lanes, n_reads // 2, 8 + 16 * n_haps, device="cuda" if use_dist else None)
+    open_s = time.perf_counter() - t0
+    elapsed, gen_ms, all_ms = timed_steps(a, sess, use_dist)
+    sizes, reads = sess.sizes()
+    offsets, (total_reads, total_bytes) = exchange_counts(reads, sizes, device="cuda")
+    if rank == 0:
+        n_launch = max(sess.n_batches(), 1)
+        alg = (sum(sizes) + 300 * (reads // 2)) / n_launch
+        kern_s = gen_ms / a.steps / 1e3 / n_launch
+        print(json.dumps({
+            "metric": "M paired reads/sec (PE150, 3 Gbp x 8 haplotypes)", "value": round(total_reads / 2 * a.steps / elapsed / 1e6, 3),
+            "unit": "M paired reads/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[3] share per GPU: %.3g Gbp reference, 8 haplotypes (%d mutations), 30x PE150 / 8"
+                                   % (n_chroms * chrom_len / 1e9, int(hs.n_mut.sum())), "pairs_per_gpu": pairs_per_gpu,
+                       "lanes_per_gpu": lanes_per_gpu, "open_seconds": round(open_s, 2),
+                       "parallelism": "lanes sharded over %d GPU(s); seed-offset and count exchanges only" % world},
+            "roofline": {"bound": "hbm", "achieved": round(alg / kern_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "illumina_kernel<LDS,2,1024,hap>",
+                         "launches_per_step": n_launch, "kernel_ms": round(kern_s * 1e3, 3)}}))
+    sess.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,12 +449,15 @@ def main():
     ap.add_argument("--genome-mbp", type=float, default=100.0)
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = choose for about 15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["illumina", "pacbio", "bgzf", "create_genome", "read_fasta"], default="illumina",
-                    help="illumina = the headline metric (BASELINE configs[1]); pacbio = configs[4]-style secondary line; "
-                         "bgzf = the device-side compressed sink on the headline workload's FASTQ")
+    ap.add_argument("--no-extras", action="store_true", help="skip the D2H-inclusive and copy-bandwidth measurements")
+    ap.add_argument("--workload", choices=["illumina", "hap", "pacbio", "bgzf", "create_genome", "read_fasta"], default="illumina",
+                    help="illumina = the headline metric (BASELINE configs[1]); hap = configs[3]'s share of one GPU; pacbio = "
+                         "configs[4]; bgzf = the device-side compressed sink on the headline workload's FASTQ")
     a = ap.parse_args()
     if a.workload == "pacbio":
         return pacbio_main(a)
+    if a.workload == "hap":
+        return hap_main(a)
     if a.workload == "bgzf":
         return bgzf_main(a)
     if a.workload == "create_genome":
@@ -337,67 +465,30 @@ def main():
     if a.workload == "read_fasta":
         return read_fasta_main(a)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % a.gpus)
-        a.gpus = world
-
+    rank, local_rank, world, use_dist = dist_setup(a)
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or os.environ.get("JK_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
     import jackalope_amd as ja
-    from jackalope_amd.sharding import lane_block, exchange_counts
+    from jackalope_amd.sharding import open_shard, exchange_counts
 
     read_length = 150
     genome = ja.synthetic_genome([int(a.genome_mbp * 1e6)], seed=2)
     total_lanes = a.lanes * world
     n_reads = 2 * a.pairs * world
     words = ja.seed_words(12345, 16 * total_lanes)
-    lane_lo, lane_hi = lane_block(rank, world, total_lanes)
-    sess = ja.illumina(genome, None, n_reads, read_length, True, n_threads=total_lanes, seed_words=words,
-                       device=local_rank, lane_begin=lane_lo, lane_end=lane_hi, _session=True)
-
-    def sync():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        sess.generate()
-    sync()
-    t0 = time.perf_counter()
-    gen_ms = 0.0
-    all_ms = 0.0
-    for _ in range(a.steps):
-        sess.generate()                      # blocks until the step's stream work is done
-        tm = sess.timing_ms()                # HIP events on the stream the kernels run on
-        gen_ms += tm["generate_kernel"]
-        all_ms += tm["total"]
-    sync()
-    elapsed = time.perf_counter() - t0
+    sess = open_shard(lambda lo, hi, off: ja.illumina(genome, None, n_reads, read_length, True, n_threads=total_lanes, seed_words=words,
+                                                      device=local_rank, lane_begin=lo, lane_end=hi, seed_offset_words=off, _session=True),
+                      total_lanes, n_reads // 2, 8, device="cuda" if use_dist else None)
+    elapsed, gen_ms, all_ms = timed_steps(a, sess, use_dist)
 
     sizes, reads_made = sess.sizes()
     pairs_rank = reads_made // 2
     fastq_bytes = sum(sizes)
 
-    # the path's only exchange: per-rank {reads, bytes R1, bytes R2} all-gathered over RCCL -> file offsets
-    # and totals; then the max over ranks of the timed region
+    # the path's only exchanges: the seed-offset all-gather inside open_shard and, here, per-rank {reads, bytes R1,
+    # bytes R2} all-gathered over RCCL -> file offsets and totals
     offsets, (total_reads, total_bytes) = exchange_counts(reads_made, sizes, device="cuda")
     total_pairs = total_reads // 2
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
 
     if rank == 0:
         value = total_pairs * a.steps / elapsed / 1e6
@@ -430,13 +521,29 @@ def main():
                                  % (1206.0 * pairs_rank / n_launch / kern_s)},
             "device_ms_per_step": round(all_ms / a.steps, 3),
         }
+    sess.close()
+    if rank == 0 and world == 1 and not a.no_extras:
+        # the second HBM denominator and the D2H-inclusive rates (never `value`)
+        copy_gbs = measured_copy_gbs()
+        out["roofline"]["peak_measured_copy"] = round(copy_gbs, 1)
+        out["roofline"]["frac_of_measured_copy"] = round(out["roofline"]["achieved"] / copy_gbs, 5)
+
+        def open_stream(compress):
+            return ja.illumina(genome, None, n_reads, read_length, True, n_threads=total_lanes, seed_words=words, device=local_rank,
+                               compress=compress, _session=True, stream_output=True)
+        out["value_incl_d2h"] = round(d2h_inclusive(open_stream, 3, 0) / 2 / 1e6, 3)
+        out["value_incl_d2h_bgzf"] = round(d2h_inclusive(open_stream, 3, 6) / 2 / 1e6, 3)
+        out["value_incl_d2h_note"] = ("M pairs/s with every launch's FASTQ copied to pinned host memory while the next launch runs "
+                                      "(streaming session, null sink); _bgzf: compressed on the device first, 0.375x the bytes")
+    if rank == 0:
         if not a.no_cpu_baseline and world == 1:            # the CPU baseline is reported at N = 1 only
             cores = min(os.cpu_count() or 1, 64)
             sample = a.cpu_sample_pairs or min(200_000 * cores, 12_000_000)     # about 15-20 s of CPU work
             p1, p2 = ja.read_profile(None, None, read_length, 1), ja.read_profile(None, None, read_length, 2)
             out["cpu_baseline"] = cpu_baseline(genome, p1, p2, read_length, sample, cores)
+            one = cpu_baseline(genome, p1, p2, read_length, max(sample // (2 * cores), 50_000), 1)
+            out["cpu_baseline_1thread"] = one
         print(json.dumps(out))
-    sess.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
