@@ -530,7 +530,7 @@ def main():
 
         def open_stream(compress):
             return ja.illumina(genome, None, n_reads, read_length, True, n_threads=total_lanes, seed_words=words, device=local_rank,
-                               compress=compress, _session=True, stream_output=True)
+                               compress=(compress or False), _session=True, stream_output=True)
         out["value_incl_d2h"] = round(d2h_inclusive(open_stream, 3, 0) / 2 / 1e6, 3)
         out["value_incl_d2h_bgzf"] = round(d2h_inclusive(open_stream, 3, 6) / 2 / 1e6, 3)
         out["value_incl_d2h_note"] = ("M pairs/s with every launch's FASTQ copied to pinned host memory while the next launch runs "
@@ -541,7 +541,7 @@ def main():
             sample = a.cpu_sample_pairs or min(200_000 * cores, 12_000_000)     # about 15-20 s of CPU work
             p1, p2 = ja.read_profile(None, None, read_length, 1), ja.read_profile(None, None, read_length, 2)
             out["cpu_baseline"] = cpu_baseline(genome, p1, p2, read_length, sample, cores)
-            one = cpu_baseline(genome, p1, p2, read_length, max(sample // (2 * cores), 50_000), 1)
+            one = cpu_baseline(genome, p1, p2, read_length, 400_000, 1)
             out["cpu_baseline_1thread"] = one
         print(json.dumps(out))
     if use_dist:
