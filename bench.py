@@ -24,6 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# Lanes per GPU: a generator launch takes 224 workgroups of 1024 lanes (the other 32 CUs run the compaction of the
+# launch before); four launches per step, 10.9 pairs per lane on the headline workload.
+DEFAULT_LANES = 4 * 224 * 1024
 
 
 def cpu_baseline(genome, prof1, prof2, read_length, sample_pairs, cores):
@@ -347,7 +350,7 @@ def pacbio_main(a):
     mbp = a.genome_mbp if a.genome_mbp != 100.0 else 3000.0
     genome = ja.synthetic_genome([int(mbp * 1e6)], seed=3)
     n_reads = int(mbp * 1e6 * 20 / 10000) * world
-    lanes = a.lanes * world
+    lanes = (a.lanes if a.lanes != DEFAULT_LANES else (1 << 20)) * world
     lens = list(range(5000, 15001, 500))
     words = ja.seed_words(12345, 16 * lanes)
     sess = open_shard(lambda lo, hi, off: ja.pacbio(genome, None, n_reads, n_threads=lanes, seed_words=words, custom_read_lengths=lens,
@@ -365,7 +368,7 @@ def pacbio_main(a):
                "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                "config": {"workload": "configs[4]: %g Mbp synthetic ref, PacBio defaults, custom read lengths uniform "
-                                      "5-15 kb (mean 10 kb), 20x per GPU" % mbp, "reads_per_gpu": n_reads // world, "lanes_per_gpu": a.lanes,
+                                      "5-15 kb (mean 10 kb), 20x per GPU" % mbp, "reads_per_gpu": n_reads // world, "lanes_per_gpu": lanes // world,
                           "parallelism": "lanes sharded over %d GPU(s), no data-path collective" % world},
                "gbases_per_sec": round(total_bytes[0] / 2 * a.steps / elapsed / 1e9, 2),
                "roofline": {"bound": "hbm", "achieved": round(alg / kern_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -406,7 +409,7 @@ def hap_main(a):
     dev.close()
     hs = random_haplotypes_flat(ref, n_haps, seed=31)
     pairs_per_gpu = n_chroms * chrom_len * 30 // 300 // 8
-    lanes_per_gpu = a.lanes if a.lanes != (1 << 20) else (1 << 18)
+    lanes_per_gpu = a.lanes if a.lanes != DEFAULT_LANES else (1 << 18)
     lanes, n_reads = lanes_per_gpu * world, 2 * pairs_per_gpu * world
     words = ja.seed_words(12345, hs.seed_budget(lanes))
     t0 = time.perf_counter()
@@ -444,7 +447,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--lanes", type=int, default=1 << 20, help="generator lanes per GPU")
+    ap.add_argument("--lanes", type=int, default=DEFAULT_LANES, help="generator lanes per GPU (default: four launches of 224 x 1024)")
     ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU (30x of 100 Mbp at PE150)")
     ap.add_argument("--genome-mbp", type=float, default=100.0)
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = choose for about 15 s of CPU work")

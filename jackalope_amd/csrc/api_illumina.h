@@ -254,7 +254,19 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
         throw Error(JK_ERR_UNSUPPORTED, "a lane would write 4 GiB or more of FASTQ per read end (" +
                     std::to_string(lane_reads.empty() ? 0 : lane_reads[0] / s.n_ends) + " reads of up to " + std::to_string(rec_max) +
                     " bytes): raise n_threads -- on the GPU n_threads is the number of generator lanes, 2^16..2^20 per device");
-    const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, 1ULL << 18, lane_cap, lane_reads, lane_seeds, quotas);
+    // Launch size.  A generator workgroup (1024 lanes) owns its CU -- 128 VGPRs x 16 waves are the whole register file --
+    // so the scan + compaction of the previous launch can only run on CUs the generator does not use.  A run of several
+    // launches therefore leaves an eighth of the CUs to it (224 + 32 on an MI355X: the two compactions of a launch,
+    // 1.6 ms each on 32 CUs, then end with the 3.2 ms generator launch they run beside, kernel trace in
+    // profiles/r02_ktrace_g224.txt; with 24 CUs they do not keep up, with 40 the generator loses more than it gains).
+    // A job that fits one launch takes every CU.
+    int n_cu = 256;
+    JK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s.device));
+    uint64_t reserve = (uint64_t)n_cu / 8;
+    if (const char* e = std::getenv("JK_COMPACT_CUS")) { const long v = std::atol(e); if (v >= 0 && v < n_cu) reserve = (uint64_t)v; }
+    uint64_t launch_lanes = (uint64_t)n_cu * JK_ILL_BLOCK;
+    if (s.n_shard > launch_lanes) launch_lanes = ((uint64_t)n_cu - reserve) * JK_ILL_BLOCK;
+    const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, launch_lanes, lane_cap, lane_reads, lane_seeds, quotas);
     const IlluminaPacked packed = pack_illumina_tables(s.tables);
     s.d_tab.upload(packed.tab);
     s.d_mm2.upload(packed.mm2);
@@ -263,7 +275,7 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
 
     s.lds_bytes = packed.tab.size() * 4;        // dynamic LDS; the kernel keeps mm2 (2 KB) in static LDS on top
     // haplotype runs add the per-lane segment table (JK_HAP_SEGS segments x 12 bytes x 1024 lanes) after the tables
-    const size_t seg_bytes = s.hap ? (size_t)JK_HAP_SEGS * 12 * JK_ILL_BLOCK : 0;
+    const size_t seg_bytes = (s.hap && !s.hap_materialised) ? (size_t)JK_HAP_SEGS * 12 * JK_ILL_BLOCK : 0;
     s.lds_tables = s.lds_bytes + seg_bytes <= 156 * 1024;
     s.lds_seg_off = s.lds_tables ? (uint32_t)align_up(s.lds_bytes, 16) : 0;
     s.lds_launch = (s.lds_tables ? align_up(s.lds_bytes, 16) : 0) + seg_bytes;
@@ -283,15 +295,16 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     P.lds_seg_off = s.lds_seg_off;
     {
         const int lb = (int)s.lds_launch;
+        auto allow = [&](const void* k) { JK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lb)); };
+#define JK_K(LDS, NE, HAP, SEG) reinterpret_cast<const void*>(&illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP, SEG>)
         if (s.lds_tables) {
-            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, JK_ILL_BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, JK_ILL_BLOCK, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 1, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<true, 2, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            allow(JK_K(true, 1, false, false)); allow(JK_K(true, 2, false, false));
+            allow(JK_K(true, 1, true, true)); allow(JK_K(true, 2, true, true));
+            allow(JK_K(true, 1, true, false)); allow(JK_K(true, 2, true, false));
         } else if (lb) {
-            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<false, 1, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
-            JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&illumina_kernel<false, 2, JK_ILL_BLOCK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lb));
+            allow(JK_K(false, 1, true, true)); allow(JK_K(false, 2, true, true));
         }
+#undef JK_K
     }
 }
 
@@ -390,9 +403,8 @@ static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min
     const uint64_t n_mut = cell_off[n_cells];
     const uint64_t blob_len = n_mut ? hs.nuc_off[n_mut] : 0;
     upload_genome(s, hs.ref, hs.nuc_blob, blob_len);          // sets s.nuc_base = offset of the blob in seq
-    std::vector<int64_t> ref_shift(n_mut);
-    std::vector<uint32_t> nuc_len(n_mut);
-    std::vector<uint64_t> nuc_dev_off(n_mut), new_pos(hs.new_pos, hs.new_pos + n_mut);
+    std::vector<HapMut> mut(n_mut);
+    const uint64_t* new_pos = hs.new_pos;
     cell_size.assign(hs.chrom_size, hs.chrom_size + n_cells);
     for (uint64_t k = 0; k < n_cells; k++) {
         const uint64_t ref_len = hs.ref.chrom_lens[k % nc];
@@ -408,13 +420,16 @@ static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min
             if (m > cell_off[k] && hs.new_pos[m] < hs.new_pos[m - 1]) throw Error(JK_ERR_ARG, "mutation new_pos must not decrease within a chromosome");
             if (smod >= 0 && have < (uint64_t)smod + 1) throw Error(JK_ERR_ARG, "mutation has fewer nucleotides than its size modifier needs");
             if (smod + 1 > 0x7fffffffLL) throw Error(JK_ERR_UNSUPPORTED, "insertion longer than 2^31 bases");
-            nuc_len[m] = smod >= 0 ? (uint32_t)(smod + 1) : 0u;
-            nuc_dev_off[m] = s.nuc_base + hs.nuc_off[m];
-            ref_shift[m] = (int64_t)hs.old_pos[m] - smod - (int64_t)hs.new_pos[m];
+            HapMut& mu = mut[m];
+            mu.new_pos = hs.new_pos[m];
+            mu.nuc_len = smod >= 0 ? (uint32_t)(smod + 1) : 0u;
+            mu.nuc_off = s.nuc_base + hs.nuc_off[m];
+            mu.ref_shift = (int64_t)hs.old_pos[m] - smod - (int64_t)hs.new_pos[m];
+            mu.pad = 0;
             // the reference run after this mutation must stay inside the chromosome
             const uint64_t run_end = (m + 1 < cell_off[k + 1]) ? hs.new_pos[m + 1] : cell_size[k];
-            const int64_t last_ref = (int64_t)run_end - 1 + ref_shift[m];
-            if (run_end > hs.new_pos[m] + nuc_len[m] && (last_ref < 0 || (uint64_t)last_ref >= ref_len))
+            const int64_t last_ref = (int64_t)run_end - 1 + mu.ref_shift;
+            if (run_end > hs.new_pos[m] + mu.nuc_len && (last_ref < 0 || (uint64_t)last_ref >= ref_len))
                 throw Error(JK_ERR_ARG, "mutation table points outside the reference chromosome");
         }
     }
@@ -436,25 +451,48 @@ static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min
         s.d_bucket.upload(bucket);
     }
     s.d_cell_off.upload(cell_off);
-    s.d_new_pos.upload(new_pos);
-    s.d_ref_shift.upload(ref_shift);
-    s.d_nuc_len.upload(nuc_len);
-    s.d_nuc_off.upload(nuc_dev_off);
+    s.d_mut.upload(mut);
     s.d_cell_size.upload(cell_size);
 }
 
 static void set_hap_params(const jk_session& s, HapDev& h, uint32_t n_haps) {
     h.cell_mut_off = s.d_cell_off.as<uint64_t>();
-    h.new_pos = s.d_new_pos.as<uint64_t>();
-    h.ref_shift = s.d_ref_shift.as<int64_t>();
-    h.nuc_len = s.d_nuc_len.as<uint32_t>();
-    h.nuc_off = s.d_nuc_off.as<uint64_t>();
+    h.mut = s.d_mut.as<HapMut>();
     h.cell_size = s.d_cell_size.as<uint64_t>();
     h.bucket_off = s.d_bucket_off.as<uint64_t>();
     h.bucket = s.d_bucket.as<uint32_t>();
     h.bc_blob = s.d_bc_blob.as<uint8_t>();
     h.bc_len = s.d_bc_len.as<uint32_t>();
     h.n_haps = n_haps;
+}
+
+// Every haplotype chromosome written out once in device memory (materialise_haps_kernel); afterwards the session's
+// genome buffer holds the n_haps x n_chroms materialised sequences and the mutation tables are released.
+static void materialise_haplotypes(jk_session& s, uint64_t n_cells, const std::vector<uint64_t>& cell_size) {
+    std::vector<uint64_t> out_off(n_cells), tile0(n_cells + 1, 0);
+    uint64_t total = 64;
+    for (uint64_t k = 0; k < n_cells; k++) {
+        out_off[k] = total;
+        total = align_up(total + cell_size[k], 64) + 64;
+        tile0[k + 1] = tile0[k] + (cell_size[k] + JK_MAT_TILE - 1) / JK_MAT_TILE;
+    }
+    if (tile0[n_cells] > 0x7fffffffULL) throw Error(JK_ERR_UNSUPPORTED, "haplotype set too large to materialise");
+    DevBuf d_hap, d_out_off, d_tile0;
+    d_hap.alloc(total);
+    JK_HIP(hipMemset(d_hap.p, 'N', total));
+    d_out_off.upload(out_off); d_tile0.upload(tile0);
+    HapDev H;
+    set_hap_params(s, H, (uint32_t)(n_cells / s.n_chroms));
+    if (tile0[n_cells])
+        hipLaunchKernelGGL(materialise_haps_kernel, dim3((uint32_t)tile0[n_cells]), dim3(256), 0, 0, s.d_seq.as<uint8_t>(),
+                           s.d_chrom_off.as<uint64_t>(), s.n_chroms, H, (uint32_t)n_cells, d_tile0.as<uint64_t>(),
+                           d_out_off.as<uint64_t>(), d_hap.as<uint8_t>());
+    JK_HIP(hipGetLastError());
+    JK_HIP(hipDeviceSynchronize());
+    s.d_seq.release(); s.d_mut.release(); s.d_bucket.release(); s.d_bucket_off.release(); s.d_cell_off.release();
+    std::swap(s.d_seq.p, d_hap.p); std::swap(s.d_seq.n, d_hap.n);
+    s.d_chrom_off.upload(out_off);           // indexed by cell from here on
+    s.hap_materialised = true;
 }
 
 // ---- illumina_hap_cpp (src/hts_illumina.cpp:662-739), one set of output files (sep_files handled by
@@ -518,6 +556,24 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
     const std::vector<uint32_t>& lane_seeds = lp.lane_seeds;
     const ZeroArray<uint32_t>& vc = lp.quotas;
 
+    {   // Materialise the haplotypes when device memory allows (the kernel then reads plain sequences at the speed of
+        // a reference-genome run; through the tables a read end pays a chain of dependent cache misses and the 4-base
+        // gear: 500 against 700 M pairs/s on BASELINE configs[3]'s share of one GPU).  Needs sum(cell sizes) bytes next
+        // to the run's pools and image; otherwise (hundreds of haplotypes of a large genome) the tables are used.
+        uint64_t mat = 64;
+        for (uint64_t k = 0; k < n_cells; k++) mat += align_up(cell_size[k], 64) + 64;
+        const uint64_t rec = record_max(max_hdr, max_chrom, s.paired, L);
+        uint64_t reads_shard = 0, reads_lane_max = 0;
+        for (uint64_t v : lane_reads) { reads_shard += v; reads_lane_max = std::max(reads_lane_max, v); }
+        const uint64_t launch = std::min<uint64_t>(s.n_shard, 256ULL * JK_ILL_BLOCK);
+        const uint64_t pools = 4 * s.n_ends * std::min<uint64_t>(launch * (reads_lane_max / s.n_ends) * rec, a.max_batch_bytes ? a.max_batch_bytes : ~0ULL);
+        const uint64_t image = s.streaming ? 0 : (reads_shard / s.n_ends) * rec * s.n_ends;
+        size_t free_b = 0, total_b = 0;
+        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        bool want = mat + pools + image + (12ULL << 30) <= free_b;
+        if (const char* e = std::getenv("JK_HAP_MATERIALISE")) want = std::atoi(e) != 0;
+        if (want) materialise_haplotypes(s, n_cells, cell_size);
+    }
     IlluminaKernelParams& P = s.kp;
     P.bc_len = 0;
     std::memset(P.barcode, 0, sizeof(P.barcode));

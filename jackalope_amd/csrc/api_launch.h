@@ -153,13 +153,16 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
         // the pool set is free again once the compaction of batch b-2 has read it
         if (b >= ns) JK_HIP(hipStreamWaitEvent(gs, s.cp_done[b - ns], 0));
         JK_HIP(hipEventRecord(s.events[ev++], gs));
-#define JK_LAUNCH(LDS, NE, HAP, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP>), dim3(grid), dim3(block), SH, gs, P)
+#define JK_LAUNCH(LDS, NE, HAP, SEG, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP, SEG>), dim3(grid), dim3(block), SH, gs, P)
+        const bool seg = s.hap && !s.hap_materialised;       // bases through the mutation tables (else: plain sequences)
         if (s.lds_tables) {
-            if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(true, 2, true, s.lds_launch); else JK_LAUNCH(true, 1, true, s.lds_launch); }
-            else       { if (s.n_ends == 2) JK_LAUNCH(true, 2, false, s.lds_launch); else JK_LAUNCH(true, 1, false, s.lds_launch); }
+            if (seg)        { if (s.n_ends == 2) JK_LAUNCH(true, 2, true, true, s.lds_launch); else JK_LAUNCH(true, 1, true, true, s.lds_launch); }
+            else if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(true, 2, true, false, s.lds_launch); else JK_LAUNCH(true, 1, true, false, s.lds_launch); }
+            else            { if (s.n_ends == 2) JK_LAUNCH(true, 2, false, false, s.lds_launch); else JK_LAUNCH(true, 1, false, false, s.lds_launch); }
         } else {
-            if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(false, 2, true, s.lds_launch); else JK_LAUNCH(false, 1, true, s.lds_launch); }
-            else       { if (s.n_ends == 2) JK_LAUNCH(false, 2, false, 0); else JK_LAUNCH(false, 1, false, 0); }
+            if (seg)        { if (s.n_ends == 2) JK_LAUNCH(false, 2, true, true, s.lds_launch); else JK_LAUNCH(false, 1, true, true, s.lds_launch); }
+            else if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(false, 2, true, false, 0); else JK_LAUNCH(false, 1, true, false, 0); }
+            else            { if (s.n_ends == 2) JK_LAUNCH(false, 2, false, false, 0); else JK_LAUNCH(false, 1, false, false, 0); }
         }
 #undef JK_LAUNCH
         JK_HIP(hipGetLastError());

@@ -59,12 +59,17 @@ struct GenomeDev {
 // which is get_char_ with size_modifier folded in on the host (nuc_len = max(size_mod + 1, 0),
 // ref_shift = old_pos - size_mod - new_pos).  Positions before a cell's first mutation read the
 // reference unshifted.  The nucleotide bytes live in the same (encoded) buffer as the genome.
+struct HapMut {                    // one mutation, 32 bytes: everything a lookup needs in one cache-line access
+    uint64_t new_pos;              // first haplotype position it covers
+    int64_t ref_shift;             // reference position = haplotype position + ref_shift behind its nucleotides
+    uint64_t nuc_off;              // offset of its nucleotides in GenomeDev::seq
+    uint32_t nuc_len;              // max(size_modifier + 1, 0)
+    uint32_t pad;
+};
 struct HapDev {
     const uint64_t* cell_mut_off;  // [n_cells + 1]
-    const uint64_t* new_pos;       // [n_mut]
-    const int64_t* ref_shift;      // [n_mut]
-    const uint32_t* nuc_len;       // [n_mut]
-    const uint64_t* nuc_off;       // [n_mut] offset in GenomeDev::seq
+    const HapMut* mut;             // [n_mut] (the separate arrays of round 1 cost four dependent cache misses per lookup; the
+                                   //  mutation tables of BASELINE configs[2..3] are 0.5-1 GB, far beyond any cache)
     const uint64_t* cell_size;     // [n_cells] haplotype chromosome sizes
     // coarse index over new_pos: for cell c and bucket j = hpos >> JK_HAP_BUCKET_SHIFT,
     // bucket[bucket_off[c] + j] = number of the cell's mutations with new_pos < (j << JK_HAP_BUCKET_SHIFT)
@@ -225,21 +230,23 @@ template <typename MIdx>
 __device__ __forceinline__ HapSeg hap_resolve(const HapDev& H, uint64_t chrom_off, uint32_t cell, MIdx& m, uint64_t hpos) {
     const uint64_t mo = H.cell_mut_off[cell];
     const int64_t n = (int64_t)(H.cell_mut_off[cell + 1] - mo);
-    while (m + 1 < n && H.new_pos[mo + m + 1] <= hpos) m++;
-    while (m >= 0 && H.new_pos[mo + m] > hpos) m--;
+    const HapMut* M = H.mut + mo;
+    while (m + 1 < n && M[m + 1].new_pos <= hpos) m++;
+    while (m >= 0 && M[m].new_pos > hpos) m--;
     HapSeg sg;
     if (m < 0) {
-        sg.begin = 0; sg.end = n > 0 ? H.new_pos[mo] : H.cell_size[cell];
+        sg.begin = 0; sg.end = n > 0 ? M[0].new_pos : H.cell_size[cell];
         sg.addr = chrom_off + hpos;
     } else {
-        const uint64_t np = H.new_pos[mo + m];
-        const uint64_t nl = H.nuc_len[mo + m];
+        const HapMut mu = M[m];
+        const uint64_t np = mu.new_pos;
+        const uint64_t nl = mu.nuc_len;
         if (hpos - np < nl) {
             sg.begin = np; sg.end = np + nl;
-            sg.addr = H.nuc_off[mo + m] + (hpos - np);
+            sg.addr = mu.nuc_off + (hpos - np);
         } else {
-            sg.begin = np + nl; sg.end = (m + 1 < n) ? H.new_pos[mo + m + 1] : H.cell_size[cell];
-            sg.addr = chrom_off + (uint64_t)((int64_t)hpos + H.ref_shift[mo + m]);
+            sg.begin = np + nl; sg.end = (m + 1 < n) ? M[m + 1].new_pos : H.cell_size[cell];
+            sg.addr = chrom_off + (uint64_t)((int64_t)hpos + mu.ref_shift);
         }
     }
     return sg;
@@ -257,9 +264,46 @@ __device__ __forceinline__ int64_t hap_search(const HapDev& H, uint32_t cell, ui
     else { lo = nb ? H.bucket[bo + nb - 1] : 0; hi = (int64_t)n; }
     while (lo < hi) {                                          // first index with new_pos > hpos
         const int64_t mid = (lo + hi) >> 1;
-        if (H.new_pos[mo + mid] <= hpos) lo = mid + 1; else hi = mid;
+        if (H.mut[mo + mid].new_pos <= hpos) lo = mid + 1; else hi = mid;
     }
     return lo - 1;
+}
+
+// HapChrom::get_chrom_full (src/hap_classes.cpp:80-116) for every cell of a haplotype set at once: the reference
+// materialises a haplotype chromosome per thread each time the thread's cursor enters a cell; here every cell is
+// written once into device memory (n_haplotypes x genome size bytes: 24 GB for BASELINE configs[3], of 288), after
+// which a haplotype run reads plain contiguous sequences.  One thread = 16 haplotype positions: the mutation under the
+// first is found through the bucket index (the 64 threads of a wave share one bucket), a run that lies in one segment
+// is one unaligned 16-byte load and one aligned 16-byte store.
+constexpr uint32_t JK_MAT_TILE = 4096;     // positions per 256-thread workgroup
+__global__ void __launch_bounds__(256)
+materialise_haps_kernel(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ ref_off, uint32_t n_chroms, HapDev H, uint32_t n_cells,
+                        const uint64_t* __restrict__ tile0 /* [n_cells + 1] first tile of each cell */,
+                        const uint64_t* __restrict__ out_off /* [n_cells] */, uint8_t* __restrict__ out) {
+    const uint64_t tile = blockIdx.x;
+    uint32_t lo = 0, hi = n_cells;               // the cell this tile belongs to: last cell with tile0 <= tile
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tile0[mid] <= tile) lo = mid; else hi = mid; }
+    const uint32_t cell = lo;
+    const uint64_t size = H.cell_size[cell];
+    const uint64_t pos0 = (tile - tile0[cell]) * JK_MAT_TILE + (uint64_t)threadIdx.x * 16u;
+    if (pos0 >= size) return;
+    const uint32_t n = size - pos0 < 16u ? (uint32_t)(size - pos0) : 16u;
+    const uint64_t coff = ref_off[cell % n_chroms];
+    int64_t m = hap_search(H, cell, pos0);
+    HapSeg sg = hap_resolve(H, coff, cell, m, pos0);
+    uint8_t* dst = out + out_off[cell] + pos0;
+    if (n == 16u && sg.end - pos0 >= 16u) {
+        uint4 v;
+        __builtin_memcpy(&v, seq + sg.addr, 16);
+        *reinterpret_cast<uint4*>(dst) = v;
+        return;
+    }
+    uint64_t at = pos0;                          // the position sg.addr stands for
+    for (uint32_t k = 0; k < n; k++) {
+        const uint64_t pos = pos0 + k;
+        if (pos >= sg.end) { sg = hap_resolve(H, coff, cell, m, pos); at = pos; }
+        dst[k] = seq[sg.addr + (pos - at)];
+    }
 }
 
 // NE = number of read ends (1 single-end, 2 paired); BLOCK = workgroup size (1024 -> 4 waves/SIMD and a
@@ -274,7 +318,10 @@ __device__ __forceinline__ int64_t hap_search(const HapDev& H, uint32_t cell, ui
 #else
 #define JK_GEN_ATTR
 #endif
-template <bool LDS_TAB, uint32_t NE, int BLOCK, bool HAP>
+// SEG = the haplotype's bases are read through the mutation tables, segment by segment; HAP without SEG = every
+// haplotype chromosome was materialised in device memory beforehand (materialise_haps_kernel): the cursor, quota, gamma
+// and barcode logic of a haplotype run over plain contiguous sequences, g.chrom_off / hdr_off indexed by cell.
+template <bool LDS_TAB, uint32_t NE, int BLOCK, bool HAP, bool SEG = HAP>
 __global__ void __launch_bounds__(BLOCK) JK_GEN_ATTR
 illumina_kernel(IlluminaKernelParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -586,10 +633,10 @@ illumina_kernel(IlluminaKernelParams P) {
             uint32_t seg_end_pp = 0xffffffffu;
             uint32_t seg_state = 0;                 // current segment | segments in the table << 8 | first unresolved position << 16
             constexpr uint32_t NO_POS = 0xffffu;
-            uint32_t* const s_seg = HAP ? reinterpret_cast<uint32_t*>(smem + P.lds_seg_off) + threadIdx.x : nullptr;
+            uint32_t* const s_seg = SEG ? reinterpret_cast<uint32_t*>(smem + P.lds_seg_off) + threadIdx.x : nullptr;
             auto seg_hpos = [&](uint32_t pp) -> uint64_t { return reverse ? (start + sp - 1 - pp) : (start + pp - bc); };
             auto seg_A = [&](uint64_t addr, uint32_t pp) -> uint64_t { return reverse ? addr + pp : addr - pp; };
-            auto seg_enter = [&](uint32_t pp) {     // HAP only; pp >= seg_end_pp: move to the next segment
+            auto seg_enter = [&](uint32_t pp) {     // SEG only; pp >= seg_end_pp: move to the next segment
                 const uint32_t cur = (seg_state & 0xffu) + 1u, n = (seg_state >> 8) & 0xffu, over = seg_state >> 16;
                 if (cur < n) {
                     const uint32_t* e = s_seg + 3u * cur * BLOCK;
@@ -605,7 +652,7 @@ illumina_kernel(IlluminaKernelParams P) {
                     seg_end_pp = avail >= (uint64_t)(0xffffffffu - pp) ? 0xffffffffu : pp + (uint32_t)avail;
                 }
             };
-            if (HAP) {
+            if (SEG) {
                 int32_t m = (int32_t)hap_search(P.h, ci, seg_hpos(bc));      // (a cell holds fewer than 2^31 mutations: checked at upload)
                 const uint64_t coff = P.g.chrom_off[ci % P.g.n_chroms];
                 uint32_t q = bc, n = 0;
@@ -628,7 +675,7 @@ illumina_kernel(IlluminaKernelParams P) {
                 A = P.g.chrom_off[ci] + (reverse ? start + sp - 1 : start - bc);
             }
             auto src_byte = [&](uint32_t pp) -> uint32_t {     // general path: one source base (pp >= bc)
-                if (HAP) { while (pp >= seg_end_pp) seg_enter(pp); }
+                if (SEG) { while (pp >= seg_end_pp) seg_enter(pp); }
                 uint32_t c = gseq[reverse ? A - pp : A + pp];
                 if (reverse) c ^= ((~c) >> 1) & 2u;                 // codes 0..3: ^2 (T<->A, C<->G); others stay non-TCAG
                 return c;
@@ -649,8 +696,8 @@ illumina_kernel(IlluminaKernelParams P) {
             uint32_t nev = 0;
             auto next_slow = [&](uint32_t pp) -> uint32_t {
                 uint32_t e = ev_any ? next_event(pp) : 0xffffffffu;
-                if (HAP) nev = e;
-                return (HAP && seg_end_pp < e) ? seg_end_pp : e;
+                if (SEG) nev = e;
+                return (SEG && seg_end_pp < e) ? seg_end_pp : e;
             };
 
             uint32_t pp = 0, op = 0;
@@ -711,7 +758,7 @@ illumina_kernel(IlluminaKernelParams P) {
                     room = pending ? 0u : (nes - pp < n_out - op ? nes - pp : n_out - op);    // pp <= nes unless pending
                     if (__builtin_amdgcn_ballot_w64(room < 4u) == 0)
                         nquads = __builtin_amdgcn_ballot_w64(room < 8u) == 0 ? 2u : 1u;
-                    else if (HAP) {
+                    else if (SEG) {
                         // Haplotypes: at 1.2 mutations per kb some lane of the wave meets a segment boundary in a third of
                         // all quads.  If segment changes are all that stands in the way, those lanes gather their four
                         // bases one by one across the boundary and the wave still takes the 4-base gear.
@@ -733,7 +780,7 @@ illumina_kernel(IlluminaKernelParams P) {
                     if (any_n) { nmlo = rlo & 0xfcfcfcfcu; nmhi = rhi & 0xfcfcfcfcu; }       // non-zero bytes: positions that are not TCAG
                 } else have_pf = false;
                 if (nquads == 1u) {
-                    if (HAP && gather_gear) {
+                    if (SEG && gather_gear) {
                         const uint64_t A0 = A; const uint32_t se0 = seg_end_pp, st0 = seg_state;
                         uint32_t w, bad;
                         if (room >= 4u) {
@@ -806,7 +853,7 @@ illumina_kernel(IlluminaKernelParams P) {
                         op += 4;
                     }
                     pp += 4u * nquads;
-                    if (HAP && seg_moved) nes = seg_end_pp < nev ? seg_end_pp : nev;     // the gathering lanes' next general position moved with their segment
+                    if (SEG && seg_moved) nes = seg_end_pp < nev ? seg_end_pp : nev;     // the gathering lanes' next general position moved with their segment
                     JK_BAL_STEP(12u * nquads);
                     continue;
                 }
@@ -835,9 +882,9 @@ illumina_kernel(IlluminaKernelParams P) {
                         }
                         pp++;
                     }
-                    if (HAP) { while (pp >= seg_end_pp && pp < sp) seg_enter(pp); }
+                    if (SEG) { while (pp >= seg_end_pp && pp < sp) seg_enter(pp); }
                     nes = pending ? 0u : (pp < bc ? pp : next_slow(pp));
-                    if (HAP && (pending || pp < bc)) nev = nes;
+                    if (SEG && (pending || pp < bc)) nev = nes;
                 }
                 uint32_t q, ch;
                 if (c < 4u) {
@@ -989,11 +1036,17 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
     // step in flight together and the next step's loads issued before this step's stores
     constexpr uint32_t LOADS = (CP_ROWS * 16) / CP_THREADS;
     const uint4* src = reinterpret_cast<const uint4*>(pool + pool_off[tile]);
-    uint4 r[LOADS];
+    // Loads run two steps ahead of the stores (two register sets, the loop is unrolled by two so that they swap roles
+    // without moves): a tile-copy on a handful of CUs -- the compaction runs on the CUs a generator launch leaves free,
+    // see plan_pools_and_alloc -- is bound by the bytes it keeps in flight per CU, and LDS limits the workgroups per CU to two.
+    uint4 ra[LOADS], rb[LOADS];
+    auto load_step = [&](uint4* r, uint32_t k0) {
+        if (k0 * 4u < max_bytes) {
 #pragma unroll
-    for (uint32_t i = 0; i < LOADS; i++) r[i] = src[t + i * CP_THREADS];
-    uint32_t buf = 0;
-    for (uint32_t k0 = 0; k0 * 4u < max_bytes; k0 += CP_ROWS, buf ^= (JK_CP_DB ? 1u : 0u)) {
+            for (uint32_t i = 0; i < LOADS; i++) r[i] = src[(size_t)k0 * 16u + t + i * CP_THREADS];
+        }
+    };
+    auto do_step = [&](const uint4* r, uint32_t k0, uint32_t buf) {
         uint32_t* L = tile_lds[buf];
         if (!JK_CP_DB && k0) __syncthreads();
 #pragma unroll
@@ -1003,10 +1056,9 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
             w[0] = r[i].x; w[1] = r[i].y; w[2] = r[i].z; w[3] = r[i].w;
         }
         __syncthreads();       // (one barrier per step: the other buffer is rewritten only after the next barrier)
-        if ((k0 + CP_ROWS) * 4u < max_bytes) {
-#pragma unroll
-            for (uint32_t i = 0; i < LOADS; i++) r[i] = src[(size_t)(k0 + CP_ROWS) * 16u + t + i * CP_THREADS];
-        }
+    };
+    auto store_step = [&](uint32_t k0, uint32_t buf) {
+        const uint32_t* L = tile_lds[buf];
 #pragma unroll
         for (uint32_t pass = 0; pass < PASSES; pass++) {
             const uint32_t l = pass * LANES_PER_PASS + t / PIECES;
@@ -1023,6 +1075,17 @@ compact_pools_kernel(const uint8_t* __restrict__ pool, const uint64_t* __restric
                 }
             }
         }
+    };
+    load_step(ra, 0);
+    load_step(rb, CP_ROWS);
+    for (uint32_t k0 = 0; k0 * 4u < max_bytes; k0 += 2 * CP_ROWS) {
+        do_step(ra, k0, 0);
+        load_step(ra, k0 + 2 * CP_ROWS);
+        store_step(k0, 0);
+        if ((k0 + CP_ROWS) * 4u >= max_bytes) break;
+        do_step(rb, k0 + CP_ROWS, JK_CP_DB ? 1u : 0u);
+        load_step(rb, k0 + 3 * CP_ROWS);
+        store_step(k0 + CP_ROWS, JK_CP_DB ? 1u : 0u);
     }
 }
 

@@ -29,6 +29,7 @@ struct jk_session {
     size_t lds_bytes = 0, lds_launch = 0, evw_set = 0;
     uint32_t lds_seg_off = 0;
     bool hap = false;
+    bool hap_materialised = false;   // haplotype chromosomes written out in d_seq (no table lookups in the kernel)
     int compress = 0;          // 0 = plain FASTQ, 1..9 = compression level
     bool bgzip = true;         // comp_method: "bgzip" (BGZF blocks) or "gzip"
     bool host_deflate = false; // comp_method "bgzip-host": BGZF blocks deflated by zlib on the host at level `compress`
@@ -42,7 +43,7 @@ struct jk_session {
     double image_scale = 1.0;  // PacBio: image capacity relative to the expected bytes (grown when the compaction ran out of image)
     uint32_t retries = 0;      // re-plans of the last generate() (pool or image too small)
     std::function<void()> replan;   // PacBio: re-plan pools after pool_scale changed
-    DevBuf d_bucket_off, d_bucket, d_cell_off, d_new_pos, d_ref_shift, d_nuc_len, d_nuc_off, d_cell_size, d_bc_blob, d_bc_len;
+    DevBuf d_bucket_off, d_bucket, d_cell_off, d_mut, d_cell_size, d_bc_blob, d_bc_len;
     // lanes of this shard
     uint64_t n_lanes_total = 0, lane_begin = 0, lane_end = 0, n_shard = 0;
     std::vector<uint64_t> pool_off_host;          // per batch-relative offsets, concatenated per batch (n+1 each)

@@ -45,6 +45,7 @@ def random_genome(ja, rng):
 
 
 def illumina_case(ja, O, rng, case):
+    os.environ["JK_HAP_MATERIALISE"] = str(case & 1)      # haplotype cases alternate between the two read paths
     g = random_genome(ja, rng)
     # sequencing system (built-in ART profile) and a read length it covers; None = the default for the length
     systems = [(None, 150), (None, 150), ("GA1", 44), ("GA2", 75), ("NS50", 75), ("HS10", 100), ("HS20", 100), ("HS25", 150),
@@ -238,6 +239,7 @@ def run(seconds, seed, kind, max_cases=None, verbose=True, first_case=0):
         if verbose and (res == "refused" or case % 25 == 0):
             print("[%5.0fs] %s: %s" % (time.time() - t0, res, desc[:200]), flush=True)
         case += 1
+    os.environ.pop("JK_HAP_MATERIALISE", None)
     return stats
 
 

@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 def test_seeded_slice(ja, O):
-    stats = fuzz_gpu.run(seconds=120, seed=1, kind="all", max_cases=60, verbose=False)
-    assert stats["ok"] >= 55
+    stats = fuzz_gpu.run(seconds=float("inf"), seed=1, kind="all", max_cases=60, verbose=False)     # bounded by cases, not by time
+    assert stats["ok"] + stats["refused"] == 60 and stats["refused"] <= 5
 
 
 @pytest.mark.parametrize("case", [746, 911])

@@ -1,6 +1,7 @@
 """GPU parity for illumina() on haplotypes (illumina_hap_cpp, src/hts_illumina.cpp:662-739): the HIP
-path reads bases through the device mutation tables, the oracle materialises each haplotype chromosome
-with get_chrom_full exactly as the reference does -- FASTQ bytes must be identical."""
+path materialises every haplotype chromosome once in device memory or, when that does not fit, reads bases through
+the device mutation tables; the oracle materialises each haplotype chromosome per thread with get_chrom_full exactly
+as the reference does -- FASTQ bytes must be identical either way."""
 import ctypes as C
 
 import numpy as np
@@ -10,6 +11,14 @@ from helpers import builder_haplotypes, job, first_diff, fastq_records
 from jackalope_amd.genome import random_haplotypes, HapSet
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["materialised", "tables"])
+def hap_mode(request, monkeypatch):
+    """Every case runs twice: with the haplotype chromosomes written out in device memory first (the default whenever
+    they fit) and through the mutation tables (what remains when they do not)."""
+    monkeypatch.setenv("JK_HAP_MATERIALISE", "1" if request.param == "materialised" else "0")
+    return request.param
 
 
 def oracle_hap(O, hs, p1, p2, words, n_reads, T, j, hap_probs, barcodes):
