@@ -409,7 +409,7 @@ def hap_main(a):
     dev.close()
     hs = random_haplotypes_flat(ref, n_haps, seed=31)
     pairs_per_gpu = n_chroms * chrom_len * 30 // 300 // 8
-    lanes_per_gpu = a.lanes if a.lanes != DEFAULT_LANES else (1 << 18)
+    lanes_per_gpu = a.lanes
     lanes, n_reads = lanes_per_gpu * world, 2 * pairs_per_gpu * world
     words = ja.seed_words(12345, hs.seed_budget(lanes))
     t0 = time.perf_counter()

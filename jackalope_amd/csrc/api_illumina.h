@@ -6,6 +6,7 @@ namespace jk {
 
 // Chromosomes (+ optionally the haplotypes' nucleotide blob) into one encoded device buffer.
 static void upload_genome(jk_session& s, const jk_ref_genome& g, const char* blob_bytes, uint64_t blob_len) {
+    PhaseTimer pt("upload_genome");
     if (g.n_chroms == 0) throw Error(JK_ERR_ARG, "reference genome has no chromosomes");
     if (g.n_chroms > 0xffffffffULL) throw Error(JK_ERR_UNSUPPORTED, "too many chromosomes");
     std::vector<uint64_t> off(g.n_chroms), len(g.n_chroms);
@@ -49,6 +50,7 @@ static inline uint8_t encode_base(char c) { return c == 'T' ? 0 : c == 'C' ? 1 :
 
 // Argument checks + error-model tables + every per-run constant of the kernel.
 static void setup_model(jk_session& s, const jk_illumina_args& a) {
+    PhaseTimer pt("model tables");
     set_compression(s, a.compress, a.comp_method);
     if (a.frag_len_shape < 1.0) throw Error(JK_ERR_UNSUPPORTED, "frag_len_shape < 1 (fragment sd > mean) is not implemented on the GPU path");
     if (!(a.frag_len_scale > 0)) throw Error(JK_ERR_ARG, "frag_len_scale must be > 0");
@@ -124,6 +126,7 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
                                   const std::vector<uint64_t>& lane_cap, const std::vector<uint64_t>& lane_reads,
                                   const std::vector<uint32_t>& lane_seeds, const ZeroArray<uint32_t>& quotas,
                                   uint64_t image_hint = 0) {
+    PhaseTimer pt("pools: plan, alloc, upload");
     uint64_t max_batch_lanes = lanes_per_batch;
     if (const char* e = std::getenv("JK_BATCH_LANES")) { const long long v = std::atoll(e); if (v >= 64) max_batch_lanes = (uint64_t)v / 64 * 64; }
     std::vector<uint64_t> pool_off;
@@ -336,6 +339,7 @@ static QuotaModel quota_model_hap(const jk_hap_set& hs, const std::vector<double
 // this session's lanes: planned here, or cut out of a plan made once for all devices of a one-shot call
 static LanePlan session_plan(jk_session& s, const QuotaModel& Q, const std::vector<uint64_t>& per_lane, SeedReader& seeds,
                              bool offset_given, uint64_t offset_words, const LanePlan* full) {
+    PhaseTimer pt("lane plan (host)");
     LanePlan lp = full ? slice_plan(*full, s.n_lanes_total, s.lane_begin, s.lane_end)
                        : plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, offset_given, offset_words);
     s.seed_words_used = lp.words_used; s.shard_seed_begin = lp.shard_begin_word; s.shard_seed_end = lp.shard_end_word;
@@ -392,6 +396,7 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
 // Mutation tables of a haplotype set -> device form (see HapDev); also uploads the genome + nucleotide blob.
 static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min_chrom, uint64_t& max_chrom,
                               std::vector<uint64_t>& cell_size) {
+    PhaseTimer pt("upload_hap_tables (all)");
     const uint64_t nh = hs.n_haps, nc = hs.ref.n_chroms;
     // ---- mutation tables -> device form (see HapDev)
     const uint64_t n_cells = nh * nc;
@@ -403,13 +408,17 @@ static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min
     const uint64_t n_mut = cell_off[n_cells];
     const uint64_t blob_len = n_mut ? hs.nuc_off[n_mut] : 0;
     upload_genome(s, hs.ref, hs.nuc_blob, blob_len);          // sets s.nuc_base = offset of the blob in seq
-    std::vector<HapMut> mut(n_mut);
+    ZeroArray<HapMut> mut;                   // (filled by host threads, cell by cell: tens of millions of records)
+    mut.assign_zero(n_mut);
     const uint64_t* new_pos = hs.new_pos;
     cell_size.assign(hs.chrom_size, hs.chrom_size + n_cells);
     for (uint64_t k = 0; k < n_cells; k++) {
-        const uint64_t ref_len = hs.ref.chrom_lens[k % nc];
         min_chrom = std::min(min_chrom, cell_size[k]);
         max_chrom = std::max(max_chrom, cell_size[k]);
+    }
+    parallel_for(n_cells, 1, [&](size_t ka, size_t kb, unsigned) {
+      for (uint64_t k = ka; k < kb; k++) {
+        const uint64_t ref_len = hs.ref.chrom_lens[k % nc];
         for (uint64_t m = cell_off[k]; m < cell_off[k + 1]; m++) {
             // size_modifier (src/hap_classes.h:314-333)
             int64_t smod = (m + 1 < cell_off[k + 1]) ? (int64_t)(hs.new_pos[m + 1] - hs.old_pos[m + 1])
@@ -432,26 +441,30 @@ static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min
             if (run_end > hs.new_pos[m] + mu.nuc_len && (last_ref < 0 || (uint64_t)last_ref >= ref_len))
                 throw Error(JK_ERR_ARG, "mutation table points outside the reference chromosome");
         }
-    }
+      }
+    });
     {   // bucket index for hap_search (HapDev::bucket): counts of mutations below each bucket boundary, + one closing entry
         std::vector<uint64_t> bucket_off(n_cells + 1, 0);
         for (uint64_t k = 0; k < n_cells; k++) bucket_off[k + 1] = bucket_off[k] + (cell_size[k] >> JK_HAP_BUCKET_SHIFT) + 2;
-        std::vector<uint32_t> bucket(bucket_off[n_cells]);
-        for (uint64_t k = 0; k < n_cells; k++) {
-            const uint64_t nb = bucket_off[k + 1] - bucket_off[k];
-            uint32_t* b = bucket.data() + bucket_off[k];
-            uint64_t m = cell_off[k];
-            for (uint64_t j = 0; j < nb; j++) {
-                const uint64_t bound = j << JK_HAP_BUCKET_SHIFT;
-                while (m < cell_off[k + 1] && new_pos[m] < bound) m++;
-                b[j] = (uint32_t)(m - cell_off[k]);
+        ZeroArray<uint32_t> bucket;
+        bucket.assign_zero(bucket_off[n_cells]);
+        parallel_for(n_cells, 1, [&](size_t ka, size_t kb, unsigned) {
+            for (uint64_t k = ka; k < kb; k++) {
+                const uint64_t nb = bucket_off[k + 1] - bucket_off[k];
+                uint32_t* b = bucket.data() + bucket_off[k];
+                uint64_t m = cell_off[k];
+                for (uint64_t j = 0; j < nb; j++) {
+                    const uint64_t bound = j << JK_HAP_BUCKET_SHIFT;
+                    while (m < cell_off[k + 1] && new_pos[m] < bound) m++;
+                    b[j] = (uint32_t)(m - cell_off[k]);
+                }
             }
-        }
+        });
         s.d_bucket_off.upload(bucket_off);
-        s.d_bucket.upload(bucket);
+        s.d_bucket.upload(bucket.data(), bucket.size());
     }
     s.d_cell_off.upload(cell_off);
-    s.d_mut.upload(mut);
+    s.d_mut.upload(mut.data(), mut.size());
     s.d_cell_size.upload(cell_size);
 }
 
@@ -469,6 +482,7 @@ static void set_hap_params(const jk_session& s, HapDev& h, uint32_t n_haps) {
 // Every haplotype chromosome written out once in device memory (materialise_haps_kernel); afterwards the session's
 // genome buffer holds the n_haps x n_chroms materialised sequences and the mutation tables are released.
 static void materialise_haplotypes(jk_session& s, uint64_t n_cells, const std::vector<uint64_t>& cell_size) {
+    PhaseTimer pt("materialise_haplotypes");
     std::vector<uint64_t> out_off(n_cells), tile0(n_cells + 1, 0);
     uint64_t total = 64;
     for (uint64_t k = 0; k < n_cells; k++) {

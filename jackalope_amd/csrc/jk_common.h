@@ -2,6 +2,9 @@
 // (part of the one translation unit jk_api.hip; see the include list there)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "../../include/jackalope_hip.h"
@@ -37,6 +40,15 @@ struct DevBuf {
     template <typename T> void upload(const T* v, size_t count) {
         alloc(count * sizeof(T));
         if (count) JK_HIP(hipMemcpy(p, v, count * sizeof(T), hipMemcpyHostToDevice));
+    }
+};
+
+// JK_TIMING=1: wall-clock of the set-up phases on stderr (where does open() spend its time?)
+struct PhaseTimer {
+    const char* what; std::chrono::steady_clock::time_point t0; bool on;
+    explicit PhaseTimer(const char* w) : what(w), t0(std::chrono::steady_clock::now()), on(std::getenv("JK_TIMING") != nullptr) {}
+    ~PhaseTimer() {
+        if (on) std::fprintf(stderr, "[jk timing] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
 };
 
