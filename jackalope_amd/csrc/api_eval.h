@@ -36,7 +36,7 @@ JK_HD void eval_one(int what, const uint64_t* in, uint64_t i, uint64_t aux, uint
             uint32_t w[8];
             for (int k = 0; k < 8; k++) w[k] = (uint32_t)in[i * 8 + k];
             EvalRng r; r.e = jk_pcg_seed(w);
-            jk_gamma_state st; st.saved = 0; st.saved_available = 0;
+            jk_gamma_state st; st.saved = 0; st.saved_available = 0; st.fail = 0;
             for (uint64_t k = 0; k < aux; k++) out[i * aux + k] = jk_d2u(jk_gamma(gp, st, r));
             break;
         }
@@ -73,10 +73,7 @@ __global__ void eval_kernel(int what, const uint64_t* in, uint64_t n, uint64_t a
 }
 
 static jk_gamma_param eval_gamma_param() {
-    jk_gamma_param gp;
-    gp.a1 = g_eval_shape - 1.0 / 3.0;
-    gp.a2 = 1.0 / std::sqrt(9.0 * gp.a1);
-    gp.beta = g_eval_scale;
+    const jk_gamma_param gp = jk_gamma_make(g_eval_shape, g_eval_scale);
     return gp;
 }
 

@@ -29,7 +29,6 @@ int jk_create_genome(uint64_t n_chroms, double len_mean, double len_sd, const do
         for (int i = 0; i < 4; i++) { if (!(pi_tcag[i] >= 0)) throw Error(JK_ERR_ARG, "pi_tcag must be >= 0"); psum += pi_tcag[i]; }
         if (!(psum > 0)) throw Error(JK_ERR_ARG, "at least one of pi_tcag must be > 0");
         const double shape = (len_mean * len_mean) / (len_sd * len_sd), scale = (len_sd * len_sd) / len_mean;
-        if (len_sd > 0 && shape < 1.0) throw Error(JK_ERR_UNSUPPORTED, "len_sd > len_mean (gamma shape < 1) is not implemented on the GPU path");
         JK_HIP(hipSetDevice(device));
         std::unique_ptr<jk_genome> G(new jk_genome);
         G->device = device;
@@ -40,8 +39,7 @@ int jk_create_genome(uint64_t n_chroms, double len_mean, double len_sd, const do
         std::vector<uint32_t> lane_seed(T * 8);
         for (uint64_t t = 0; t < T; t++) sr.take8(&lane_seed[t * 8]);           // mt_seeds (src/pcg.h:63-71)
         G->seed_words_used = sr.pos;
-        jk_gamma_param gp;
-        gp.a1 = shape - 1.0 / 3.0; gp.a2 = 1.0 / std::sqrt(9.0 * gp.a1); gp.beta = scale;
+        const jk_gamma_param gp = jk_gamma_make(len_sd > 0 ? shape : 1.0, scale);      // (host draws: pow falls back to libm itself)
         std::vector<uint64_t> len(n_chroms), start(2 * n_chroms), inc(2 * T), adv(T * 64 * 4);
         std::vector<uint32_t> lane_of(n_chroms);
         // omp for schedule(static): contiguous blocks, the first n_chroms % T threads get one more
@@ -57,7 +55,7 @@ int jk_create_genome(uint64_t n_chroms, double len_mean, double len_sd, const do
                 a[0] = (uint64_t)(map[k].mult >> 64); a[1] = (uint64_t)map[k].mult;
                 a[2] = (uint64_t)(map[k].plus >> 64); a[3] = (uint64_t)map[k].plus;
             }
-            jk_gamma_state gs{0.0, 0};
+            jk_gamma_state gs{0.0, 0, 0};
             for (uint64_t i = 0; i < per_lane[t]; i++, c++) {
                 uint64_t L;
                 if (len_sd > 0) {

@@ -52,7 +52,7 @@ static inline uint8_t encode_base(char c) { return c == 'T' ? 0 : c == 'C' ? 1 :
 static void setup_model(jk_session& s, const jk_illumina_args& a) {
     PhaseTimer pt("model tables");
     set_compression(s, a.compress, a.comp_method);
-    if (a.frag_len_shape < 1.0) throw Error(JK_ERR_UNSUPPORTED, "frag_len_shape < 1 (fragment sd > mean) is not implemented on the GPU path");
+    if (!(a.frag_len_shape > 0)) throw Error(JK_ERR_ARG, "frag_len_shape must be > 0");
     if (!(a.frag_len_scale > 0)) throw Error(JK_ERR_ARG, "frag_len_scale must be > 0");
     s.paired = a.paired != 0;
     s.n_ends = s.paired ? 2 : 1;
@@ -75,12 +75,7 @@ static void setup_model(jk_session& s, const jk_illumina_args& a) {
     P.read_len = L; P.n_ends = s.n_ends; P.paired = s.paired; P.matepair = (s.paired && a.matepair) ? 1 : 0;
     P.ev_words = s.ev_words;
     P.frag_min = a.frag_len_min; P.frag_max = a.frag_len_max;
-    {   // gamma_distribution<double>::param_type::_M_initialize (random.tcc:2330-2346), alpha >= 1
-        const double a1 = a.frag_len_shape - 1.0 / 3.0;
-        P.gp.a1 = a1;
-        P.gp.a2 = 1.0 / std::sqrt(9.0 * a1);
-        P.gp.beta = a.frag_len_scale;
-    }
+    P.gp = jk_gamma_make(a.frag_len_shape, a.frag_len_scale);     // gamma_distribution<double>::param_type::_M_initialize (random.tcc:2330-2346)
     const double insp[2] = {a.ins_prob1, a.ins_prob2}, delp[2] = {a.del_prob1, a.del_prob2};
     for (uint32_t r = 0; r < 2; r++) {
         // u > (ins + del) -> match ; else u > ins -> deletion ; else insertion (hts_illumina.cpp:133-144)
@@ -97,7 +92,6 @@ static void setup_model(jk_session& s, const jk_illumina_args& a) {
 }
 
 static void check_barcode(const std::string& bc, uint32_t L) {
-    if (bc.size() > (size_t)JK_MAX_BARCODE) throw Error(JK_ERR_UNSUPPORTED, "barcodes longer than 32 bases are not implemented on the GPU path");
     if (bc.size() >= L) throw Error(JK_ERR_ARG, "barcode must be shorter than the read length");
 }
 

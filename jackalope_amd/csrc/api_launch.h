@@ -207,7 +207,7 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
     uint64_t result[4] = {0, 0, 0, 0};
     JK_HIP(hipMemcpy(result, s.d_result.p, sizeof(result), hipMemcpyDeviceToHost));
     const uint32_t err = (uint32_t)result[0];
-    if (err & JK_KERR_PB_ALPHA) throw Error(JK_ERR_UNSUPPORTED, "chi-square shape n/2 < 1 (chi2_params_n) is not implemented on the GPU path");
+    if (err & JK_KERR_GAMMA_MATH) throw Error(JK_ERR_UNSUPPORTED, "a fragment-length draw with frag_len_shape < 1 needed pow() beyond the range implemented on the GPU (|log(u) / shape| >= 512)");
     if (err & JK_KERR_PB_MATH) throw Error(JK_ERR_UNSUPPORTED, "a PacBio parameter led to an exp/pow argument outside the range implemented on the GPU");
     if (err & JK_KERR_PB_TOO_LONG) throw Error(JK_ERR_UNSUPPORTED, "a read was longer than the GPU path's cap (9 sigma of the log-normal, or it needed > 2x its length in reference positions)");
     if (err & JK_KERR_PB_SPACE) throw Error(JK_ERR_UNSUPPORTED, "a read position lies outside the reference's read buffer (undefined there: a read as long as its chromosome or a clipped duplicate with no earlier, longer read on its thread) or needs more chromosome than there is");

@@ -29,7 +29,7 @@
 
 namespace jk {
 
-constexpr int JK_MAX_BARCODE = 32;
+constexpr int JK_MAX_BARCODE = 480;      // a barcode is shorter than the read, and reads are at most 480 long (JK_MAX_EVW)
 constexpr int JK_MAX_EVW = 16;         // 64-bit words of indel-event bitmaps per read end (positions < 1024)
 constexpr uint32_t JK_HAP_BUCKET_SHIFT = 10;   // 1024 haplotype positions per bucket of the mutation index
 constexpr uint32_t JK_HAP_SEGS = 3;    // segments of a read window kept in the per-lane LDS table (haplotype runs)
@@ -39,6 +39,7 @@ enum : uint32_t {
     JK_KERR_IMAGE_FULL = 64u,          // the compacted FASTQ image would not fit the buffer allocated for it (PacBio: see plan_pools_common)
     JK_KERR_TOO_MANY_DELETIONS = 1u,   // a read end needed more source positions than the event bitmaps hold
     JK_KERR_POOL_OVERFLOW = 2u,        // internal: a lane wrote past its pool region
+    JK_KERR_GAMMA_MATH = 128u,         // gamma shape < 1: pow(u, 1/shape) left the transcribed main path of glibc's pow (|y log u| >= 512)
 };
 
 struct GenomeDev {
@@ -388,7 +389,7 @@ illumina_kernel(IlluminaKernelParams P) {
 #endif
     LaneRng rng;
     rng.e = jk_pcg_limbs(jk_pcg_seed(P.seeds + (size_t)lane * 8));
-    jk_gamma_state gst; gst.saved = 0.0; gst.saved_available = 0;
+    jk_gamma_state gst; gst.saved = 0.0; gst.saved_available = 0; gst.fail = 0;
 
     const uint32_t L = P.read_len;
     uint32_t bc = P.bc_len;                      // HAP: per haplotype, reloaded when the cursor moves
@@ -442,6 +443,7 @@ illumina_kernel(IlluminaKernelParams P) {
             }
             const uint64_t chrom_len = HAP ? P.h.cell_size[ci] : P.g.chrom_len[ci];
             double gl = jk_gamma(P.gp, gst, rng);
+            if (gst.fail) { err |= JK_KERR_GAMMA_MATH; break; }
             frag_len = (uint64_t)gl;
             if (frag_len < P.frag_min) frag_len = P.frag_min;
             if (frag_len > P.frag_max) frag_len = P.frag_max;

@@ -280,8 +280,21 @@ JK_HD double jk_log(double x) {
 // distribution object persists inside the reference's per-thread filler copy
 // (src/hts_illumina.h:301,393).
 // ---------------------------------------------------------------------------------------------
-struct jk_gamma_state { double saved; int saved_available; };
-struct jk_gamma_param { double a1; double a2; double beta; };   // a1 = alpha - 1/3, a2 = 1/sqrt(9*a1)
+struct jk_gamma_state { double saved; int saved_available; int fail; };   // fail: a pow() argument left the transcribed main path
+// a1 = malpha - 1/3, a2 = 1/sqrt(9*a1) with malpha = alpha (alpha >= 1) or alpha + 1 (alpha < 1: the draw is then
+// multiplied by pow(u, 1/alpha), random.tcc:2336-2338,2380-2388)
+struct jk_gamma_param { double a1; double a2; double beta; double inv_alpha; int small; };
+JK_HD jk_gamma_param jk_gamma_make(double alpha, double beta) {
+    jk_gamma_param p;
+    const double malpha = alpha < 1.0 ? alpha + 1.0 : alpha;
+    p.a1 = malpha - 1.0 / 3.0;
+    p.a2 = 1.0 / __builtin_sqrt(9.0 * p.a1);
+    p.beta = beta;
+    p.small = alpha < 1.0;
+    p.inv_alpha = 1.0 / alpha;
+    return p;
+}
+JK_HD double jk_pow(double x, double y, bool* ok);      // jk_math2.h (glibc's pow, main path)
 
 JK_HD double jk_sqrt(double v) { return __builtin_sqrt(v); }   // IEEE correctly rounded on both sides
 
@@ -312,5 +325,13 @@ JK_HD double jk_gamma(const jk_gamma_param& p, jk_gamma_state& st, Rng& rng) {
         u = jk_canonical(rng());
     } while (u > 1.0 - 0.0331 * n * n * n * n &&
              (jk_log(u) > (0.5 * n * n + p.a1 * (1.0 - v + jk_log(v)))));
-    return p.a1 * v * p.beta;
+    if (!p.small) return p.a1 * v * p.beta;
+    do u = jk_canonical(rng()); while (u == 0.0);
+    bool ok = true;
+    double pw = jk_pow(u, p.inv_alpha, &ok);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (!ok) { pw = __builtin_pow(u, p.inv_alpha); ok = true; }      // host: libm itself (what the reference calls)
+#endif
+    if (!ok) st.fail = 1;
+    return pw * p.a1 * v * p.beta;
 }

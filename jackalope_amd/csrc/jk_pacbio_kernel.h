@@ -163,8 +163,8 @@ pacbio_kernel(PacbioKernelParams P) {
 
     LaneRng rng;
     rng.e = jk_pcg_limbs(jk_pcg_seed(P.seeds + (size_t)lane * 8));
-    jk_gamma_state ln_st; ln_st.saved = 0.0; ln_st.saved_available = 0;     // lognormal_distribution::_M_nd
-    jk_gamma_state chi_st; chi_st.saved = 0.0; chi_st.saved_available = 0;  // chi_squared -> gamma -> _M_nd
+    jk_gamma_state ln_st; ln_st.saved = 0.0; ln_st.saved_available = 0; ln_st.fail = 0;     // lognormal_distribution::_M_nd
+    jk_gamma_state chi_st; chi_st.saved = 0.0; chi_st.saved_available = 0; chi_st.fail = 0;  // chi_squared -> gamma -> _M_nd
 
     const uint64_t quota = P.lane_reads[lane];
     uint64_t made = 0, in_pool = 0;
@@ -245,15 +245,13 @@ pacbio_kernel(PacbioKernelParams P) {
         double sc;
         if (Ld <= P.cs[2]) { sc = P.cs[0] * Ld - P.cs[1]; if (sc < 0.001) sc = 0.001; }
         else { bool ok = true; sc = P.cs[3] / jk_pow(Ld, P.cs[4], &ok); if (!ok) err |= JK_KERR_PB_MATH; }
-        jk_gamma_param gp;
-        {
-            const double alpha = n / 2;
-            if (alpha < 1.0) { err |= JK_KERR_PB_ALPHA; break; }
-            gp.a1 = alpha - 1.0 / 3.0; gp.a2 = 1.0 / jk_sqrt(9.0 * gp.a1); gp.beta = 1.0;
-        }
+        // chi_squared_distribution(n) = 2 * gamma(n / 2, 1) (random.h: _M_gd(__n / 2), operator() returns 2 * _M_gd(urng));
+        // n / 2 < 1 takes the gamma sampler's pow branch
+        const jk_gamma_param gp = jk_gamma_make(n / 2, 1.0);
         double passes = 2 * jk_gamma(gp, chi_st, rng);
         const double thr = P.thr_tab[L < P.thr_cap ? (uint32_t)L : P.thr_cap];
         while (passes > thr) passes = 2 * jk_gamma(gp, chi_st, rng);
+        if (chi_st.fail) { err |= JK_KERR_PB_MATH; break; }
         passes *= sc;
         passes += 1;
         if (passes > P.max_passes_d) passes = P.max_passes_d;

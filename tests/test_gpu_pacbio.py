@@ -58,6 +58,10 @@ def test_other_error_models(ja, O):
     check_ref(ja, O, g, 300, 8, {"max_passes": 5, "sqrt_params": (0.8, 0.3), "norm_params": (0.1, 0.35)})
     check_ref(ja, O, g, 300, 8, {"lognorm_read_length": (0.35, -500.0, 3000.0), "min_read_length": 400})
     check_ref(ja, O, g, 300, 8, {"norm_params": (-3.0, 0.2)})      # far-tail branch of trunc_norm
+    # chi-square with n < 2 degrees of freedom (the reference clamps n at 0.001, src/hts_pacbio.h:158-160, so it does go
+    # there): gamma shape n / 2 < 1, libstdc++'s pow branch
+    check_ref(ja, O, g, 400, 16, {"chi2_params_n": (0.0001, 0.5, 5500)})
+    check_ref(ja, O, g, 400, 16, {"chi2_params_n": (0.0, 0.0, 5500)})      # n clamped to 0.001
 
 
 def test_non_tcag_bases_are_copied_like_the_reference(ja, O):

@@ -56,7 +56,7 @@ def test_matepair(ja, O):
     check(ja, O, g, 150, 3000, 17, job(matepair=True, frag_mean=1000.0, frag_sd=150.0))
 
 
-@pytest.mark.parametrize("barcode", ["ACGT", "TTGACCAN", "A" * 32])
+@pytest.mark.parametrize("barcode", ["ACGT", "TTGACCAN", "A" * 32, "GATTACA" * 9, "TCAG" * 37])      # the last: 148 of 150 bases
 def test_barcodes(ja, O, barcode):
     g = ja.synthetic_genome([50_000], seed=5)
     check(ja, O, g, 150, 2000, 9, job(barcode=barcode))
@@ -115,6 +115,10 @@ def test_gamma_shapes(ja, O):
     g = ja.synthetic_genome([300_000], seed=13)
     check(ja, O, g, 150, 4000, 20, job(frag_mean=300.0, frag_sd=300.0))     # shape 1
     check(ja, O, g, 150, 4000, 20, job(frag_mean=5000.0, frag_sd=500.0))    # shape 100
+    # shape < 1 (any positive frag_sd is legal, R/hts_illumina.R:658): libstdc++ then draws with shape + 1 and multiplies
+    # by pow(u, 1 / shape) (random.tcc:2380-2388)
+    check(ja, O, g, 150, 6000, 33, job(frag_mean=400.0, frag_sd=500.0))     # shape 0.64
+    check(ja, O, g, 150, 6000, 33, job(frag_mean=300.0, frag_sd=900.0, frag_len_max=5000))     # shape 0.11
 
 
 @pytest.mark.parametrize("matepair", [False, True])
@@ -196,8 +200,6 @@ def test_compressed_sinks(ja, O, tmp_path):
 def test_unsupported_inputs_fail_loudly(ja):
     g = ja.synthetic_genome([10_000], seed=16)
     words = ja.seed_words(1, 64)
-    with pytest.raises(ja.JackalopeHipError, match="shape"):
-        ja.illumina(g, None, 100, 150, True, n_threads=2, seed_words=words, frag_mean=100, frag_sd=200, _session=True)
     with pytest.raises(ja.JackalopeHipError, match="seed"):
         ja.illumina(g, None, 100, 150, True, n_threads=4, seed_words=words[:8], _session=True)
 
