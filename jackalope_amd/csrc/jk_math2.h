@@ -21,13 +21,42 @@ static constexpr uint64_t JK_EXP_T[256] = JK_EXP_TAB;
 static constexpr double JK_PLOG_A[7] = JK_POWLOG_POLY;
 static constexpr double JK_PLOG_T[384] = JK_POWLOG_TAB;     // {invc, logc, logctail} x 128
 
-// Core shared by exp and pow: exp(x + xtail) with the sign/scale handling of the normal range.
-// Returns false when |x| is outside the range glibc handles without its special-case path.
+// glibc's specialcase() of exp / pow (sysdeps/ieee754/dbl-64/e_exp.c, e_pow.c): 512 <= |x| < 1024, where the scale
+// 2^k alone would over- or underflow.  libm's FMA build fuses the sum of the k > 0 branch and leaves those of the k < 0
+// branch unfused (found and checked bit for bit against this image's libm over the whole range,
+// tests/test_host_primitives.py).
+JK_HD double jk_exp_specialcase(double tmp, uint64_t sbits, uint64_t ki) {
+    if ((ki & 0x80000000ULL) == 0) {
+        sbits -= 1009ULL << 52;                      // k > 0: the exponent of scale might have overflowed by <= 460
+        const double scale = jk_u2d(sbits);
+        return 0x1p1009 * __builtin_fma(scale, tmp, scale);
+    }
+    sbits += 1022ULL << 52;                          // k < 0: special care in the subnormal range
+    const double scale = jk_u2d(sbits);
+    double y = scale + scale * tmp;
+    if (__builtin_fabs(y) < 1.0) {
+        double one = 1.0;
+        if (y < 0.0) one = -1.0;
+        double lo = scale - y + scale * tmp;
+        const double hi = one + y;
+        lo = one - hi + y + lo;
+        y = (hi + lo) - one;
+        if (y == 0.0) y = jk_u2d(sbits & 0x8000000000000000ULL);
+    }
+    return 0x1p-1022 * y;
+}
+
+// Core shared by exp and pow: exp(x + xtail).  (Always true now: kept as a status for callers that distinguish.)
 JK_HD bool jk_exp_core(double x, double xtail, double* out) {
-    const uint32_t abstop = (uint32_t)(jk_d2u(x) >> 52) & 0x7ffu;
+    uint32_t abstop = (uint32_t)(jk_d2u(x) >> 52) & 0x7ffu;
+    bool special = false;
     if (abstop - 0x3c9u >= 0x3fu) {
         if (abstop - 0x3c9u >= 0x80000000u) { *out = 1.0 + x; return true; }   // |x| < 2^-54
-        return false;                                                         // |x| >= 512: specialcase / overflow
+        if (abstop >= 0x409u) {                                                // |x| >= 1024 (inf / nan are the callers' business)
+            *out = (jk_d2u(x) >> 63) ? 0.0 : __builtin_inf();                  // __math_uflow(0) / __math_oflow(0)
+            return true;
+        }
+        special = true;                                                        // 512 <= |x| < 1024
     }
     const double InvLn2N = JK_EXP_C[0], Shift = JK_EXP_C[1], NegLn2hiN = JK_EXP_C[2], NegLn2loN = JK_EXP_C[3];
     const double C2 = JK_EXP_C[4], C3 = JK_EXP_C[5], C4 = JK_EXP_C[6], C5 = JK_EXP_C[7];
@@ -48,6 +77,7 @@ JK_HD bool jk_exp_core(double x, double xtail, double* out) {
     const double pt = __builtin_fma(p, r2, t);
     const double r4 = r2 * r2;
     const double tmp = __builtin_fma(q, r4, pt);
+    if (special) { *out = jk_exp_specialcase(tmp, sbits, ki); return true; }
     const double scale = jk_u2d(sbits);
     *out = __builtin_fma(tmp, scale, scale);
     return true;

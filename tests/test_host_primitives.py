@@ -185,9 +185,14 @@ def pacbio_math_inputs(n, seed):
     rng = np.random.default_rng(seed)
     d = {}
     d["exp"] = np.concatenate([rng.normal(0, 5, n), rng.uniform(-20, 20, n), rng.normal(9.8, 0.3, n),
-                               np.array([0.0, 1e-20, -1e-20, 1.0, -1.0])])
-    bx = np.concatenate([rng.uniform(0.001, 1, n), np.full(n, 2.0), rng.uniform(1, 1e6, n)])
-    ey = np.concatenate([rng.uniform(0.6, 12, n), rng.uniform(-40, 10, n), np.full(n, 1.4691051212330266)])
+                               rng.uniform(-1100, -500, n), rng.uniform(500, 1100, n),
+                               np.array([0.0, 1e-20, -1e-20, 1.0, -1.0, -745.2, -744.9, 709.7, 709.9, -1e300, 1e300])])
+    # (the last two blocks: results near and beyond the under- / overflow thresholds -- glibc's specialcase() -- as the
+    #  gamma sampler's pow(u, 1 / shape) produces them for tiny shapes)
+    bx = np.concatenate([rng.uniform(0.001, 1, n), np.full(n, 2.0), rng.uniform(1, 1e6, n), rng.uniform(0, 1, n) ** 4 + 1e-19,
+                         rng.uniform(1.5, 40, n)])
+    ey = np.concatenate([rng.uniform(0.6, 12, n), rng.uniform(-40, 10, n), np.full(n, 1.4691051212330266), rng.uniform(1, 2500, n),
+                         rng.uniform(100, 1200, n)])
     xy = np.empty(2 * bx.size)
     xy[0::2], xy[1::2] = bx, ey
     d["pow"] = xy
@@ -220,8 +225,8 @@ def test_pacbio_math_matches_host_libm_and_x87(O, built, name, op, per):
     x = pacbio_math_inputs(500_000, 3)[name]
     a = eval2(_abi.lib().jk_host_eval, op, x.view(np.uint64), per)
     b = orc2(O, op, x.view(np.uint64), per)
-    ok = a != np.uint64(2 ** 64 - 1)          # ~0 marks "outside the transcribed main path"
-    assert ok.mean() > 0.99
+    ok = a != np.uint64(2 ** 64 - 1)          # ~0 marks "outside the transcribed paths"
+    assert ok.mean() > 0.99 and (ok.all() or name not in ("exp", "pow"))
     assert (a[ok] == b[ok]).all(), "%s differs on %d inputs" % (name, int((a[ok] != b[ok]).sum()))
 
 
