@@ -246,3 +246,48 @@ def test_nmath_restatements_against_scipy(O, built):
     p = np.random.default_rng(1).uniform(0, 1, 20000)
     q = eval2(_abi.lib().jk_host_eval, _abi.OP_QNORM, p.view(np.uint64)).view(np.float64)
     assert np.max(np.abs(q - ndtri(p)) / np.maximum(np.abs(ndtri(p)), 1e-12)) < 1e-13
+
+
+def test_nmath_published_check_values_and_exact_references(O, built):
+    """What can be pinned without R.  (1) Wichura's AS 241 paper gives check values for PPND16: the restated qnorm must
+    return them.  (2) pnorm (Cody 1969) and qchisq -- R's own are accurate to about 1e-15 -- are compared with 50-digit
+    references (mpmath) over the ranges the PacBio set-up uses them in: the thresholds qchisq(0.9925, n) for n from the
+    clamp 0.001 up to chi2_params_n's cap, pnorm over the truncated-normal bounds.  A 1-ulp difference from R in one of
+    these table values changes a read only when a draw falls into that ulp (probability ~1e-16 per draw)."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    # (1) AS 241, "Test data": PPND16(0.25), PPND16(0.001), PPND16(1e-20)
+    as241 = [(0.25, -0.6744897501960817), (0.001, -3.090232306167814), (1e-20, -9.262340089798408)]
+    ps = np.array([p for p, _ in as241])
+    got_host = eval2(_abi.lib().jk_host_eval, _abi.OP_QNORM, ps.view(np.uint64)).view(np.float64)
+    got_orc = orc2(O, _abi.OP_QNORM, ps.view(np.uint64)).view(np.float64)
+    for (p, want), a, b in zip(as241, got_host, got_orc):
+        assert a == b
+        assert abs(a - want) <= 5e-16 * abs(want), (p, a, want)       # (the paper prints 16 significant digits)
+    # by symmetry and at the branch points of the algorithm (|q| = 0.425, r = 5)
+    for p in (0.5, 0.075, 0.925, float(mp.exp(-25)), 1 - 2.0 ** -30):
+        want = float(mp.sqrt(2) * mp.erfinv(2 * mp.mpf(p) - 1))
+        a = eval2(_abi.lib().jk_host_eval, _abi.OP_QNORM, np.array([p]).view(np.uint64)).view(np.float64)[0]
+        assert abs(a - want) <= 4e-16 * max(abs(want), 1e-300) + (1e-16 if p == 0.5 else 0), (p, a, want)
+    # (2) pnorm against exact values, lower tail to the underflow edge
+    O.lib().orc_pnorm.restype = C.c_double
+    O.lib().orc_pnorm.argtypes = [C.c_double]
+    worst = 0.0
+    for x in list(np.linspace(-37.5, 8.2, 300)) + [0.0, -0.67448, 0.66291, -5.656854, 5.656854, -1e-8]:
+        want = mp.ncdf(mp.mpf(float(x)))
+        got = O.lib().orc_pnorm(float(x))
+        rel = abs((mp.mpf(got) - want) / want)
+        worst = max(worst, float(rel))
+    assert worst < 8e-16, worst                 # Cody's rational approximations: a few ulp at most
+    O.lib().orc_qchisq.restype = C.c_double
+    O.lib().orc_qchisq.argtypes = [C.c_double, C.c_double]
+    worst = 0.0
+    for df in [0.001, 0.01, 0.1, 0.5, 1.0, 1.5, 2.0] + list(np.linspace(2.5, 13.0, 43)) + [25.0, 100.0]:
+        half = mp.mpf(df) / 2
+        f = lambda x: mp.gammainc(half, 0, x / 2, regularized=True) - mp.mpf("0.9925")
+        guess = O.lib().orc_qchisq(0.9925, float(df))
+        want = mp.findroot(f, mp.mpf(guess))
+        worst = max(worst, float(abs((mp.mpf(guess) - want) / want)))
+    # measured: 9.8e-14 (the Newton solve stops at 1e-13; R's own qgamma stops its single Newton polish at |dp| < 1e-15 p from
+    # an AS 91 start good to 5e-7, i.e. it is not exact to the ulp either): agreement with R to ~1e-13 is the honest claim
+    assert worst < 2e-13, worst
