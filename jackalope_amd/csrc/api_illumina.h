@@ -109,6 +109,53 @@ static std::vector<uint64_t> plan_lanes(jk_session& s, uint64_t n_threads, uint6
     return per_lane;
 }
 
+// The per-lane, per-cell read quotas into d_chrom_reads: uploaded when the planner made them on the host, else made
+// on the device from the deferred reads_per_group tasks (chrom_split_kernel; tasks it hands back are redone here).
+static void upload_quotas(jk_session& s, const LanePlan& lp, const QuotaModel& Q) {
+    if (!lp.deferred) { s.d_chrom_reads.upload(lp.quotas.data(), lp.quotas.size()); return; }
+    PhaseTimer pt("quotas on the device");
+    const uint64_t nh = Q.hap ? Q.n_haps : 1, G = Q.n_chroms, n_cells = nh * G;
+    s.d_chrom_reads.alloc(std::max<uint64_t>(n_cells * s.n_shard, 1) * 4);
+    JK_HIP(hipMemset(s.d_chrom_reads.p, 0, std::max<uint64_t>(n_cells * s.n_shard, 1) * 4));
+    const uint64_t nt = lp.n_tasks();
+    if (nt == 0 || G == 0) return;
+    std::vector<double> cp(nh * (G - 1) + 1, 0.0), cq(nh * (G - 1) + 1, 0.0);
+    std::vector<uint8_t> ck(nh * (G - 1) + 1, 1);
+    for (uint64_t h = 0; h < nh; h++) {
+        const GroupChain& ch = Q.chrom_chain[h];
+        for (uint64_t g = 0; g + 1 < G; g++) {
+            cp[h * (G - 1) + g] = ch.p[g]; ck[h * (G - 1) + g] = ch.kind[g];
+            const double p12 = ch.p[g] <= 0.5 ? ch.p[g] : 1.0 - ch.p[g];
+            cq[h * (G - 1) + g] = -std::log(1 - p12);           // BinomDraw's q, by the host's libm
+        }
+    }
+    DevBuf d_words, d_n, d_lane, d_hap, d_p, d_q, d_k, d_redo;
+    d_words.upload(lp.task_words); d_n.upload(lp.task_n); d_lane.upload(lp.task_lane); d_hap.upload(lp.task_hap);
+    d_p.upload(cp); d_q.upload(cq); d_k.upload(ck);
+    d_redo.alloc(nt * 4);
+    JK_HIP(hipMemset(d_redo.p, 0, nt * 4));
+    SplitChainDev C{d_p.as<double>(), d_q.as<double>(), d_k.as<uint8_t>(), (uint32_t)G};
+    hipLaunchKernelGGL(chrom_split_kernel, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, 0, nt, d_words.as<uint32_t>(), d_n.as<uint32_t>(),
+                       d_lane.as<uint32_t>(), d_hap.as<uint32_t>(), C, Q.n_ends, (uint64_t)s.n_shard, s.d_chrom_reads.as<uint32_t>(),
+                       d_redo.as<uint32_t>());
+    JK_HIP(hipGetLastError());
+    std::vector<uint32_t> redo(nt);
+    JK_HIP(hipMemcpy(redo.data(), d_redo.p, nt * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> idx;
+    for (uint64_t k = 0; k < nt; k++) if (redo[k]) idx.push_back(k);
+    if (idx.empty()) return;
+    // binomials outside the waiting-time branch (many reads per lane and chromosome): libstdc++ itself, on host threads
+    std::vector<uint32_t> vals(idx.size() * G);
+    run_tasks_on_host(Q, lp, idx.data(), idx.size(), vals.data());
+    DevBuf d_idx, d_vals;
+    d_idx.upload(idx); d_vals.upload(vals);
+    hipLaunchKernelGGL(chrom_split_patch_kernel, dim3((uint32_t)((idx.size() * G + 255) / 256)), dim3(256), 0, 0, (uint64_t)idx.size(),
+                       d_idx.as<uint64_t>(), d_vals.as<uint32_t>(), d_lane.as<uint32_t>(), d_hap.as<uint32_t>(), (uint32_t)G,
+                       (uint64_t)s.n_shard, s.d_chrom_reads.as<uint32_t>());
+    JK_HIP(hipGetLastError());
+    JK_HIP(hipDeviceSynchronize());
+}
+
 // Pools: tiles of 64 lanes (one wave), every lane of a tile gets the capacity of the tile's largest
 // quota of maximal records; a batch is a run of whole tiles.  Then all device buffers.
 // lane_cap[l] = pool bytes lane l may need.  Plans batches/tiles and allocates everything that does not
@@ -117,9 +164,10 @@ static std::vector<uint64_t> plan_lanes(jk_session& s, uint64_t n_threads, uint6
 // reads) is far above it, the image buffer is allocated for the hint with headroom instead, and the compaction
 // refuses to write past it (JK_KERR_IMAGE_FULL).
 static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint64_t lanes_per_batch,
-                                  const std::vector<uint64_t>& lane_cap, const std::vector<uint64_t>& lane_reads,
-                                  const std::vector<uint32_t>& lane_seeds, const ZeroArray<uint32_t>& quotas,
+                                  const std::vector<uint64_t>& lane_cap, const LanePlan& lp, const QuotaModel& Q,
                                   uint64_t image_hint = 0) {
+    const std::vector<uint64_t>& lane_reads = lp.lane_reads;
+    const std::vector<uint32_t>& lane_seeds = lp.lane_seeds;
     PhaseTimer pt("pools: plan, alloc, upload");
     uint64_t max_batch_lanes = lanes_per_batch;
     if (const char* e = std::getenv("JK_BATCH_LANES")) { const long long v = std::atoll(e); if (v >= 64) max_batch_lanes = (uint64_t)v / 64 * 64; }
@@ -185,7 +233,7 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     }
     s.d_seeds.upload(lane_seeds);
     s.d_lane_reads.upload(lane_reads);
-    s.d_chrom_reads.upload(quotas.data(), quotas.size());
+    upload_quotas(s, lp, Q);
     s.d_pool_off.upload(pool_off);
     for (uint32_t e = 0; e < s.n_ends; e++) {
         s.d_pool[0][e].alloc(max_pool + 64 + CP_SLACK);
@@ -238,9 +286,8 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     return max_lanes;
 }
 
-static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const std::vector<uint64_t>& lane_reads,
-                                 uint64_t rec_max, const std::vector<uint32_t>& lane_seeds,
-                                 const ZeroArray<uint32_t>& quotas) {
+static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const LanePlan& lp, const QuotaModel& Q, uint64_t rec_max) {
+    const std::vector<uint64_t>& lane_reads = lp.lane_reads;
     // A batch is one generator launch.  Default: 2^18 lanes = one 1024-thread workgroup on each of the
     // 256 CUs, so every launch is a single full wave of workgroups and the pool compaction of batch b
     // (HBM-bound, second stream) runs under the generator of batch b+1 (ALU-bound).
@@ -263,7 +310,7 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     if (const char* e = std::getenv("JK_COMPACT_CUS")) { const long v = std::atol(e); if (v >= 0 && v < n_cu) reserve = (uint64_t)v; }
     uint64_t launch_lanes = (uint64_t)n_cu * JK_ILL_BLOCK;
     if (s.n_shard > launch_lanes) launch_lanes = ((uint64_t)n_cu - reserve) * JK_ILL_BLOCK;
-    const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, launch_lanes, lane_cap, lane_reads, lane_seeds, quotas);
+    const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, launch_lanes, lane_cap, lp, Q);
     const IlluminaPacked packed = pack_illumina_tables(s.tables);
     s.d_tab.upload(packed.tab);
     s.d_mm2.upload(packed.mm2);
@@ -330,12 +377,14 @@ static QuotaModel quota_model_hap(const jk_hap_set& hs, const std::vector<double
     }
     return Q;
 }
+// chromosome-level splits on the device unless JK_HOST_SPLITS=1
+static bool defer_splits() { const char* e = std::getenv("JK_HOST_SPLITS"); return !(e && std::atoi(e) != 0); }
 // this session's lanes: planned here, or cut out of a plan made once for all devices of a one-shot call
 static LanePlan session_plan(jk_session& s, const QuotaModel& Q, const std::vector<uint64_t>& per_lane, SeedReader& seeds,
                              bool offset_given, uint64_t offset_words, const LanePlan* full) {
     PhaseTimer pt("lane plan (host)");
     LanePlan lp = full ? slice_plan(*full, s.n_lanes_total, s.lane_begin, s.lane_end)
-                       : plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, offset_given, offset_words);
+                       : plan_lane_quotas(Q, per_lane, s.lane_begin, s.lane_end, seeds, offset_given, offset_words, defer_splits());
     s.seed_words_used = lp.words_used; s.shard_seed_begin = lp.shard_begin_word; s.shard_seed_end = lp.shard_end_word;
     return lp;
 }
@@ -375,16 +424,14 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
     // ---- lanes, quotas, seeds: same order of seed consumption as src/hts.h:334-353 (mt_seeds, then per lane
     // IlluminaOneGenome::add_n_reads, src/hts_illumina.h:410-418); see jk_plan.h
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, a.n_reads);
-    LanePlan lp = session_plan(s, quota_model_ref(g, s.n_ends), per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
-    const std::vector<uint64_t>& lane_reads = lp.lane_reads;
-    const std::vector<uint32_t>& lane_seeds = lp.lane_seeds;
-    const ZeroArray<uint32_t>& chrom_reads = lp.quotas;
+    const QuotaModel Q = quota_model_ref(g, s.n_ends);
+    LanePlan lp = session_plan(s, Q, per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
 
     IlluminaKernelParams& P = s.kp;
     P.bc_len = (uint32_t)barcode.size();
     std::memset(P.barcode, 0, sizeof(P.barcode));
     for (size_t k = 0; k < barcode.size(); k++) P.barcode[k] = encode_base(barcode[k]);
-    plan_pools_and_alloc(s, a, lane_reads, record_max(max_hdr, max_chrom, s.paired, L), lane_seeds, chrom_reads);
+    plan_pools_and_alloc(s, a, lp, Q, record_max(max_hdr, max_chrom, s.paired, L));
 }
 
 // Mutation tables of a haplotype set -> device form (see HapDev); also uploads the genome + nucleotide blob.
@@ -559,10 +606,9 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
     // each read maker's own add_n_reads (halves the pair count again when paired; its result is never
     // read by the haplotype path, but it consumes 8 seed words when it has reads).  See jk_plan.h.
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, n_reads);
-    LanePlan lp = session_plan(s, quota_model_hap(hs, hap_probs, s.n_ends, s.paired), per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
+    const QuotaModel Q = quota_model_hap(hs, hap_probs, s.n_ends, s.paired);
+    LanePlan lp = session_plan(s, Q, per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
     const std::vector<uint64_t>& lane_reads = lp.lane_reads;
-    const std::vector<uint32_t>& lane_seeds = lp.lane_seeds;
-    const ZeroArray<uint32_t>& vc = lp.quotas;
 
     {   // Materialise the haplotypes when device memory allows (the kernel then reads plain sequences at the speed of
         // a reference-genome run; through the tables a read end pays a chain of dependent cache misses and the 4-base
@@ -586,7 +632,7 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
     P.bc_len = 0;
     std::memset(P.barcode, 0, sizeof(P.barcode));
     set_hap_params(s, P.h, (uint32_t)nh);
-    plan_pools_and_alloc(s, a, lane_reads, record_max(max_hdr, max_chrom, s.paired, L), lane_seeds, vc);
+    plan_pools_and_alloc(s, a, lp, Q, record_max(max_hdr, max_chrom, s.paired, L));
 }
 
 }  // namespace jk

@@ -97,7 +97,7 @@ static void job_plan_next(jk_job& j) {
         case jk_job::PB_HAP: Q = quota_model_hap(*j.haps, j.cur_probs, 1, false); break;
     }
     if (Q.n_chroms == 0) throw Error(JK_ERR_ARG, "reference genome has no chromosomes");
-    j.plan = plan_lane_quotas(Q, per_lane, 0, j.T, j.seeds, false, 0);
+    j.plan = plan_lane_quotas(Q, per_lane, 0, j.T, j.seeds, false, 0, defer_splits());
     j.planned = true;
     j.next_file++;
 }

@@ -126,8 +126,8 @@ static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a
 }
 
 static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioHostModel& M, size_t max_hdr, uint64_t max_chrom,
-                          const std::vector<uint64_t>& lane_reads, const std::vector<uint32_t>& lane_seeds,
-                          const ZeroArray<uint32_t>& quotas) {
+                          const LanePlan& lp, const QuotaModel& Q) {
+    const std::vector<uint64_t>& lane_reads = lp.lane_reads;
     // pools: sized for reads of length len_hi; the kernel checks before every record and the session retries
     // with a larger scale if a lane ran out (s.pool_scale)
     const uint64_t rec = max_hdr + n_digits(max_chrom) + 3 + 2 * M.len_hi + 8;
@@ -139,7 +139,7 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     for (uint64_t l = 0; l < s.n_shard; l++) n_reads_shard += lane_reads[l];
     const uint64_t image_hint = (uint64_t)((double)(n_reads_shard * (max_hdr + n_digits(max_chrom) + 3 + 2 * (uint64_t)std::ceil(M.len_mean) + 8)) * s.image_scale);
     const uint32_t max_lanes = plan_pools_common(s, max_batch_bytes ? max_batch_bytes : (48ULL << 30), 1ULL << 18,
-                                                 lane_cap, lane_reads, lane_seeds, quotas, image_hint);
+                                                 lane_cap, lp, Q, image_hint);
     s.ev_words = (uint32_t)((2 * M.len_cap + 64 + 31) / 32);
     s.d_ev2.alloc((size_t)s.ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
     s.d_len_thresh.upload(M.len_thresh); s.d_len_alias.upload(M.len_alias); s.d_lens.upload(M.lens);
@@ -187,11 +187,12 @@ static void open_pacbio_ref(jk_session& s, const jk_ref_genome& g, const jk_pacb
     upload_headers(s, hdrs, max_hdr);
     // lanes, quotas, seeds (src/hts.h:334-353 with n_read_ends = 1; PacBioOneGenome::add_n_reads, hts_pacbio.h:499-503)
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, a.n_reads);
-    LanePlan lp = session_plan(s, quota_model_ref(g, 1), per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
+    const QuotaModel Q = quota_model_ref(g, 1);
+    LanePlan lp = session_plan(s, Q, per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
     std::shared_ptr<LanePlan> plan = std::make_shared<LanePlan>(std::move(lp));
     const uint64_t mbb = a.max_batch_bytes;
     jk_session* sp = &s;
-    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, plan->lane_reads, plan->lane_seeds, plan->quotas); };
+    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, *plan, Q); };
     s.replan();
 }
 
@@ -219,12 +220,13 @@ static void open_pacbio_hap(jk_session& s, const jk_hap_set& hs, const jk_pacbio
     upload_headers(s, hdrs, max_hdr);
     // PacBioHaplotypes::add_n_reads (src/hts_pacbio.h:683-700)
     std::vector<uint64_t> per_lane = plan_lanes(s, a.n_threads, a.lane_begin, a.lane_end, n_reads);
-    LanePlan lp = session_plan(s, quota_model_hap(hs, hap_probs, 1, false), per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
+    const QuotaModel Q = quota_model_hap(hs, hap_probs, 1, false);
+    LanePlan lp = session_plan(s, Q, per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
     std::shared_ptr<LanePlan> plan = std::make_shared<LanePlan>(std::move(lp));
     set_hap_params(s, s.kpb.h, (uint32_t)nh);
     const uint64_t mbb = a.max_batch_bytes;
     jk_session* sp = &s;
-    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, plan->lane_reads, plan->lane_seeds, plan->quotas); };
+    s.replan = [=]() { finish_pacbio(*sp, mbb, M, max_hdr, max_chrom, *plan, Q); };
     s.replan();
 }
 

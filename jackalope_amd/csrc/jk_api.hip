@@ -42,6 +42,7 @@
 #include "jk_bgzf_kernel.h"
 #include "jk_genome_kernel.h"
 #include "jk_fasta_kernel.h"
+#include "jk_plan_kernel.h"
 #include "jk_common.h"
 #include "jk_session.h"
 #include "api_illumina.h"

@@ -93,16 +93,34 @@ struct LanePlan {
     ZeroArray<uint32_t> quotas;            // [cell][lane of the shard]
     uint64_t words_used = 0;               // position in the seed stream after the last lane that was planned
     uint64_t shard_begin_word = 0, shard_end_word = 0;   // add_n_reads words of this shard's lanes: [begin, end) in the stream
+    // Deferred chromosome-level splits (`defer` of plan_lane_quotas): instead of `quotas`, the list of reads_per_group
+    // calls that make it -- per call its 8 seed words, its read count, its lane and haplotype -- in lane order.  The
+    // sessions run them on the device (chrom_split_kernel: 10^8 waiting-time binomials are nothing there, and the
+    // 0.8 GB quota table of a 2^21-lane run never crosses the host link).
+    bool deferred = false;
+    std::vector<uint32_t> task_words, task_n, task_lane, task_hap;
+    uint64_t n_tasks() const { return task_n.size(); }
 };
 
 // Lanes [begin, end) of a plan made for lanes [0, T): what one device of a multi-device run takes.
 inline LanePlan slice_plan(const LanePlan& full, uint64_t T, uint64_t begin, uint64_t end) {
     LanePlan P;
-    const uint64_t n = end - begin, n_cells = T ? full.quotas.size() / T : 0;
+    const uint64_t n = end - begin, n_cells = (T && !full.deferred) ? full.quotas.size() / T : 0;
     P.lane_seeds.assign(full.lane_seeds.begin() + begin * 8, full.lane_seeds.begin() + end * 8);
     P.lane_reads.assign(full.lane_reads.begin() + begin, full.lane_reads.begin() + end);
-    P.quotas.assign_zero((size_t)n_cells * n);
-    for (uint64_t c = 0; c < n_cells; c++) std::memcpy(P.quotas.data() + c * n, full.quotas.data() + c * T + begin, n * 4);
+    if (full.deferred) {
+        P.deferred = true;
+        const size_t a = std::lower_bound(full.task_lane.begin(), full.task_lane.end(), (uint32_t)begin) - full.task_lane.begin();
+        const size_t b = std::lower_bound(full.task_lane.begin(), full.task_lane.end(), (uint32_t)end) - full.task_lane.begin();
+        P.task_words.assign(full.task_words.begin() + a * 8, full.task_words.begin() + b * 8);
+        P.task_n.assign(full.task_n.begin() + a, full.task_n.begin() + b);
+        P.task_hap.assign(full.task_hap.begin() + a, full.task_hap.begin() + b);
+        P.task_lane.resize(b - a);
+        for (size_t k = a; k < b; k++) P.task_lane[k - a] = full.task_lane[k] - (uint32_t)begin;
+    } else {
+        P.quotas.assign_zero((size_t)n_cells * n);
+        for (uint64_t c = 0; c < n_cells; c++) std::memcpy(P.quotas.data() + c * n, full.quotas.data() + c * T + begin, n * 4);
+    }
     P.words_used = full.words_used; P.shard_begin_word = full.shard_begin_word; P.shard_end_word = full.shard_end_word;
     return P;
 }
@@ -124,14 +142,16 @@ inline uint32_t words_after_hap_split(const QuotaModel& M, const uint64_t* hr) {
 
 // pairs[t] = the lane's count as add_n_reads sees it (reads / n_ends); per_lane[t] = reads of lane t.
 inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t>& per_lane, uint64_t lane_begin, uint64_t lane_end,
-                                 SeedReader& seeds, bool offset_given, uint64_t offset_words) {
+                                 SeedReader& seeds, bool offset_given, uint64_t offset_words, bool defer = false) {
     using namespace plan_detail;
     const uint64_t T = per_lane.size(), n_shard = lane_end - lane_begin;
     const uint64_t nh = M.hap ? M.n_haps : 1, nc = M.n_chroms, n_cells = nh * nc;
     LanePlan P;
     P.lane_seeds.assign(n_shard * 8, 0);
     P.lane_reads.assign(n_shard, 0);
-    P.quotas.assign_zero((size_t)n_cells * n_shard);
+    if (n_shard > 0xffffffffULL) defer = false;
+    P.deferred = defer;
+    if (!defer) P.quotas.assign_zero((size_t)n_cells * n_shard);
     for (uint64_t l = 0; l < n_shard; l++) P.lane_reads[l] = per_lane[lane_begin + l];
     auto pairs_of = [&](uint64_t t) { return per_lane[t] / M.n_ends; };
     auto store_cell = [&](uint64_t cell0, uint64_t l) {
@@ -149,6 +169,14 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
         struct Task { uint64_t n; uint32_t w[8]; uint32_t h; uint64_t l; };
         std::vector<Task> tasks;
         auto run_tasks = [&]() {                   // the chromosome-level splits collected so far, on host threads
+            if (defer) {
+                for (const Task& k : tasks) {
+                    P.task_words.insert(P.task_words.end(), k.w, k.w + 8);
+                    P.task_n.push_back((uint32_t)k.n); P.task_lane.push_back((uint32_t)k.l); P.task_hap.push_back(k.h);
+                }
+                tasks.clear();
+                return;
+            }
             parallel_for(tasks.size(), 2048, [&](size_t a, size_t b, unsigned) {
                 BinomDraw bd2;
                 for (size_t i = a; i < b; i++) {
@@ -212,6 +240,18 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
         if (offset_given && offset_words != off_of(lane_begin)) throw Error(JK_ERR_ARG, "seed-word offset does not match the lanes before this shard");
         const uint64_t end_off = off_of(T);
         if (end_off > NW) throw Error(JK_ERR_SEEDS, "seed source exhausted: the path needs more 32-bit sub-seed words than were supplied");
+        if (defer) {
+            uint64_t nt = 0;
+            for (uint64_t l = 0; l < n_shard; l++) nt += pairs_of(lane_begin + l) > 0;
+            P.task_words.resize(nt * 8); P.task_n.resize(nt); P.task_lane.resize(nt); P.task_hap.assign(nt, 0);
+            uint64_t k = 0;
+            for (uint64_t l = 0; l < n_shard; l++) {
+                const uint64_t t = lane_begin + l, n = pairs_of(t);
+                if (n == 0) continue;
+                std::memcpy(&P.task_words[k * 8], W + off_of(t), 32);
+                P.task_n[k] = (uint32_t)n; P.task_lane[k] = (uint32_t)l; k++;
+            }
+        } else
         parallel_for(n_shard, 4096, [&](size_t a, size_t b, unsigned) {
             BinomDraw bd;
             for (size_t l = a; l < b; l++) {
@@ -297,6 +337,28 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
     }
     if (off[R] > NW) throw Error(JK_ERR_SEEDS, "seed source exhausted: the path needs more 32-bit sub-seed words than were supplied");
     // chromosome-level splits of this shard's lanes
+    if (defer) {
+        std::vector<uint64_t> first_task(n_shard + 1, 0);
+        for (uint64_t l = 0; l < n_shard; l++) {
+            uint64_t c = 0;
+            for (uint64_t h = 0; h < nh; h++) c += hr_own[l * nh + h] > 0;
+            first_task[l + 1] = first_task[l] + c;
+        }
+        const uint64_t nt = first_task[n_shard];
+        P.task_words.resize(nt * 8); P.task_n.resize(nt); P.task_lane.resize(nt); P.task_hap.resize(nt);
+        parallel_for(n_shard, 4096, [&](size_t a, size_t b, unsigned) {
+            for (size_t l = a; l < b; l++) {
+                uint64_t o = off[lane_begin + l - first] + 8, k = first_task[l];
+                for (uint64_t h = 0; h < nh; h++) {
+                    const uint32_t n = hr_own[l * nh + h];
+                    if (n == 0) continue;
+                    std::memcpy(&P.task_words[k * 8], W + o, 32);
+                    P.task_n[k] = n; P.task_lane[k] = (uint32_t)l; P.task_hap[k] = (uint32_t)h;
+                    o += 8; k++;
+                }
+            }
+        });
+    } else
     parallel_for(n_shard, 512, [&](size_t a, size_t b, unsigned) {
         BinomDraw bd;
         for (size_t l = a; l < b; l++) {
@@ -315,6 +377,23 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
     P.shard_begin_word = off[lane_begin - first]; P.shard_end_word = off[lane_end - first];
     seeds.pos = P.words_used;
     return P;
+}
+
+// Run (a subset of) deferred tasks on the host: quotas[(hap * n_chroms + g) * stride + lane].  `only` = task indices
+// (nullptr: all).  Used for the tasks the device kernel hands back (a binomial outside libstdc++'s waiting-time branch).
+inline void run_tasks_on_host(const QuotaModel& M, const LanePlan& P, const uint64_t* only, uint64_t n_only, uint32_t* out /* [n][n_chroms] */) {
+    const uint64_t nc = M.n_chroms;
+    const uint64_t n = only ? n_only : P.n_tasks();
+    parallel_for(n, 256, [&](size_t a, size_t b, unsigned) {
+        BinomDraw bd;
+        for (size_t i = a; i < b; i++) {
+            const uint64_t k = only ? only[i] : i;
+            uint32_t* dst = out + i * nc;
+            for (uint64_t g = 0; g < nc; g++) dst[g] = 0;
+            split_with_chain(P.task_n[k], M.chrom_chain[M.hap ? P.task_hap[k] : 0], &P.task_words[k * 8], bd,
+                             [dst, mult = M.n_ends](size_t g, uint64_t v) { dst[g] = (uint32_t)(v * mult); });
+        }
+    });
 }
 
 }  // namespace jk
