@@ -35,9 +35,21 @@ int jk_plan_lane_quotas(int32_t hap, uint32_t n_ends, int32_t maker_halves, cons
         if (Q.hap) Q.hap_chain = GroupChain(std::vector<double>(hap_probs, hap_probs + n_haps));
         for (uint64_t h = 0; h < Q.n_haps; h++) Q.chrom_chain.emplace_back(std::vector<double>(chrom_probs + h * n_chroms, chrom_probs + (h + 1) * n_chroms));
         SeedReader r{*seeds};
-        LanePlan lp = plan_lane_quotas(Q, per_lane, lane_begin, lane_end, r, offset_given != 0, offset_words);
+        // JK_PLAN_HOOK_DEFER=1 (tests): plan the way the sessions do -- the chromosome-level splits as a task list (what
+        // chrom_split_kernel runs on the device) -- and run the tasks here, on the host
+        const bool defer = std::getenv("JK_PLAN_HOOK_DEFER") != nullptr;
+        LanePlan lp = plan_lane_quotas(Q, per_lane, lane_begin, lane_end, r, offset_given != 0, offset_words, defer);
         if (lane_seeds) std::memcpy(lane_seeds, lp.lane_seeds.data(), lp.lane_seeds.size() * 4);
-        if (quotas) std::memcpy(quotas, lp.quotas.data(), lp.quotas.size() * 4);
+        if (quotas && !lp.deferred) std::memcpy(quotas, lp.quotas.data(), lp.quotas.size() * 4);
+        if (quotas && lp.deferred) {
+            const uint64_t n_shard = lane_end - lane_begin, nc = n_chroms, nt = lp.n_tasks();
+            std::memset(quotas, 0, (size_t)Q.n_haps * nc * n_shard * 4);
+            std::vector<uint32_t> vals(nt * nc);
+            run_tasks_on_host(Q, lp, nullptr, 0, vals.data());
+            for (uint64_t k = 0; k < nt; k++)
+                for (uint64_t g = 0; g < nc; g++)
+                    quotas[((uint64_t)(Q.hap ? lp.task_hap[k] : 0) * nc + g) * n_shard + lp.task_lane[k]] = vals[k * nc + g];
+        }
         if (words3) { words3[0] = lp.words_used; words3[1] = lp.shard_begin_word; words3[2] = lp.shard_end_word; }
     });
 }

@@ -130,7 +130,8 @@ static void upload_quotas(jk_session& s, const LanePlan& lp, const QuotaModel& Q
         }
     }
     DevBuf d_words, d_n, d_lane, d_hap, d_p, d_q, d_k, d_redo;
-    d_words.upload(lp.task_words); d_n.upload(lp.task_n); d_lane.upload(lp.task_lane); d_hap.upload(lp.task_hap);
+    d_words.upload(lp.task_words.data(), lp.task_words.size()); d_n.upload(lp.task_n.data(), lp.task_n.size());
+    d_lane.upload(lp.task_lane.data(), lp.task_lane.size()); d_hap.upload(lp.task_hap.data(), lp.task_hap.size());
     d_p.upload(cp); d_q.upload(cq); d_k.upload(ck);
     d_redo.alloc(nt * 4);
     JK_HIP(hipMemset(d_redo.p, 0, nt * 4));

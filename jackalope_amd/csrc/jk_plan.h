@@ -20,6 +20,8 @@
 //    chromosome-level splits of this process's lanes run on host threads.
 #pragma once
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <random>
 #include <thread>
@@ -28,6 +30,18 @@
 #include "jk_host.h"
 
 namespace jk {
+
+// JK_TIMING=1: wall-clock of the planner's phases on stderr
+struct PlanTimer {
+    const char* what; std::chrono::steady_clock::time_point t0; bool on;
+    explicit PlanTimer(const char* w) : what(w), t0(std::chrono::steady_clock::now()), on(std::getenv("JK_TIMING") != nullptr) {}
+    void lap(const char* next) {
+        const auto t1 = std::chrono::steady_clock::now();
+        if (on) std::fprintf(stderr, "[jk timing]   plan: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        what = next; t0 = t1;
+    }
+    ~PlanTimer() { lap(""); }
+};
 
 // Number of host threads for planning work.
 inline unsigned plan_threads(size_t n_items, size_t min_per_thread) {
@@ -98,7 +112,7 @@ struct LanePlan {
     // sessions run them on the device (chrom_split_kernel: 10^8 waiting-time binomials are nothing there, and the
     // 0.8 GB quota table of a 2^21-lane run never crosses the host link).
     bool deferred = false;
-    std::vector<uint32_t> task_words, task_n, task_lane, task_hap;
+    ZeroArray<uint32_t> task_words, task_n, task_lane, task_hap;       // (filled by host threads: first touch is theirs)
     uint64_t n_tasks() const { return task_n.size(); }
 };
 
@@ -110,13 +124,17 @@ inline LanePlan slice_plan(const LanePlan& full, uint64_t T, uint64_t begin, uin
     P.lane_reads.assign(full.lane_reads.begin() + begin, full.lane_reads.begin() + end);
     if (full.deferred) {
         P.deferred = true;
-        const size_t a = std::lower_bound(full.task_lane.begin(), full.task_lane.end(), (uint32_t)begin) - full.task_lane.begin();
-        const size_t b = std::lower_bound(full.task_lane.begin(), full.task_lane.end(), (uint32_t)end) - full.task_lane.begin();
-        P.task_words.assign(full.task_words.begin() + a * 8, full.task_words.begin() + b * 8);
-        P.task_n.assign(full.task_n.begin() + a, full.task_n.begin() + b);
-        P.task_hap.assign(full.task_hap.begin() + a, full.task_hap.begin() + b);
-        P.task_lane.resize(b - a);
-        for (size_t k = a; k < b; k++) P.task_lane[k - a] = full.task_lane[k] - (uint32_t)begin;
+        const uint32_t* tl = full.task_lane.data();
+        const size_t nt = full.task_lane.size();
+        const size_t a = std::lower_bound(tl, tl + nt, (uint32_t)begin) - tl;
+        const size_t b = end > 0xffffffffULL ? nt : (size_t)(std::lower_bound(tl, tl + nt, (uint32_t)end) - tl);
+        P.task_words.assign_zero((b - a) * 8); P.task_n.assign_zero(b - a); P.task_hap.assign_zero(b - a); P.task_lane.assign_zero(b - a);
+        if (b > a) {
+            std::memcpy(P.task_words.data(), full.task_words.data() + a * 8, (b - a) * 32);
+            std::memcpy(P.task_n.data(), full.task_n.data() + a, (b - a) * 4);
+            std::memcpy(P.task_hap.data(), full.task_hap.data() + a, (b - a) * 4);
+        }
+        for (size_t k = a; k < b; k++) P.task_lane[k - a] = tl[k] - (uint32_t)begin;
     } else {
         P.quotas.assign_zero((size_t)n_cells * n);
         for (uint64_t c = 0; c < n_cells; c++) std::memcpy(P.quotas.data() + c * n, full.quotas.data() + c * T + begin, n * 4);
@@ -168,11 +186,12 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
         }
         struct Task { uint64_t n; uint32_t w[8]; uint32_t h; uint64_t l; };
         std::vector<Task> tasks;
+        std::vector<uint32_t> cb_words, cb_n, cb_lane, cb_hap;      // deferred tasks, grown as the callback delivers
         auto run_tasks = [&]() {                   // the chromosome-level splits collected so far, on host threads
             if (defer) {
                 for (const Task& k : tasks) {
-                    P.task_words.insert(P.task_words.end(), k.w, k.w + 8);
-                    P.task_n.push_back((uint32_t)k.n); P.task_lane.push_back((uint32_t)k.l); P.task_hap.push_back(k.h);
+                    cb_words.insert(cb_words.end(), k.w, k.w + 8);
+                    cb_n.push_back((uint32_t)k.n); cb_lane.push_back((uint32_t)k.l); cb_hap.push_back(k.h);
                 }
                 tasks.clear();
                 return;
@@ -213,6 +232,10 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
                 if ((M.maker_halves ? hr[h] / 2 : hr[h]) > 0 && nc > 0) seeds.take8(w);
         }
         run_tasks();
+        if (defer) {
+            auto take = [](ZeroArray<uint32_t>& dst, const std::vector<uint32_t>& src) { dst.assign_zero(src.size()); if (!src.empty()) std::memcpy(dst.data(), src.data(), src.size() * 4); };
+            take(P.task_words, cb_words); take(P.task_n, cb_n); take(P.task_lane, cb_lane); take(P.task_hap, cb_hap);
+        }
         P.words_used = seeds.pos;
         if (lane_begin >= T) P.shard_begin_word = seeds.pos;
         if (lane_end >= T) P.shard_end_word = seeds.pos;
@@ -243,7 +266,7 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
         if (defer) {
             uint64_t nt = 0;
             for (uint64_t l = 0; l < n_shard; l++) nt += pairs_of(lane_begin + l) > 0;
-            P.task_words.resize(nt * 8); P.task_n.resize(nt); P.task_lane.resize(nt); P.task_hap.assign(nt, 0);
+            P.task_words.assign_zero(nt * 8); P.task_n.assign_zero(nt); P.task_lane.assign_zero(nt); P.task_hap.assign_zero(nt);
             uint64_t k = 0;
             for (uint64_t l = 0; l < n_shard; l++) {
                 const uint64_t t = lane_begin + l, n = pairs_of(t);
@@ -266,6 +289,7 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
         return P;
     }
 
+    PlanTimer tm("set-up");
     // haplotypes.  need[t] = words lane t takes / 8; off[t] = its first word.  Planned range: [first, last).
     const uint64_t first = offset_given ? lane_begin : 0;
     const uint64_t last = offset_given ? lane_end : T;
@@ -286,12 +310,16 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
         for (uint64_t i = from; i < R; i++) off[i + 1] = off[i] + 8ull * need[i];
     };
     rebuild(0);
+    tm.lap("hap-level splits");
     // fix-point: compute every lane's real need at its current offset; a lane whose need differs moves all later
     // offsets.  Lanes before the first difference are final, so each pass makes progress; the usual case is one pass.
     uint64_t stable = 0;                               // lanes [0, stable) are final
+    bool go_sequential = false;
     for (int pass = 0; stable < R; pass++) {
-        if (pass >= 6) {
-            // pathological inputs (few reads per lane and many haplotypes): finish sequentially
+        if (pass >= 6 || go_sequential) {
+            // few reads per lane and haplotype (a haplotype without reads is then common): every such lane moves all
+            // later offsets and a parallel pass only gets as far as the first of them -- the chain off[t+1] = off[t] +
+            // need(t, words at off[t]) is walked on one thread (0.7 us per lane)
             BinomDraw bd;
             std::vector<uint64_t> hr(nh);
             for (uint64_t i = stable; i < R; i++) {
@@ -310,6 +338,7 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
             break;
         }
         std::atomic<uint64_t> first_bad{R};
+        std::atomic<uint64_t> n_bad{0};
         const uint64_t s0 = stable;
         parallel_for(R - s0, 2048, [&](size_t a, size_t b, unsigned) {
             BinomDraw bd;
@@ -325,6 +354,7 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
                 }
                 if (nd != need[i]) {
                     need[i] = nd;
+                    n_bad.fetch_add(1, std::memory_order_relaxed);
                     uint64_t cur = first_bad.load();
                     while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
                 }
@@ -334,8 +364,10 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
         if (fb == R) { stable = R; break; }
         rebuild(fb);                                   // lane fb itself was computed at a final offset
         stable = fb + 1;
+        if (n_bad.load() > 4) go_sequential = true;    // (each further pass would cost a sweep over all remaining lanes)
     }
     if (off[R] > NW) throw Error(JK_ERR_SEEDS, "seed source exhausted: the path needs more 32-bit sub-seed words than were supplied");
+    tm.lap("chromosome-level tasks");
     // chromosome-level splits of this shard's lanes
     if (defer) {
         std::vector<uint64_t> first_task(n_shard + 1, 0);
@@ -345,7 +377,7 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
             first_task[l + 1] = first_task[l] + c;
         }
         const uint64_t nt = first_task[n_shard];
-        P.task_words.resize(nt * 8); P.task_n.resize(nt); P.task_lane.resize(nt); P.task_hap.resize(nt);
+        P.task_words.assign_zero(nt * 8); P.task_n.assign_zero(nt); P.task_lane.assign_zero(nt); P.task_hap.assign_zero(nt);
         parallel_for(n_shard, 4096, [&](size_t a, size_t b, unsigned) {
             for (size_t l = a; l < b; l++) {
                 uint64_t o = off[lane_begin + l - first] + 8, k = first_task[l];

@@ -102,8 +102,17 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=["host", "tasks"])
+def split_mode(request, monkeypatch):
+    """quotas made by the planner itself / as the deferred task list the sessions hand to the device kernel (run on the
+    host here, through the same hook)"""
+    if request.param == "tasks":
+        monkeypatch.setenv("JK_PLAN_HOOK_DEFER", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("case", range(len(CASES)))
-def test_planner_matches_literal_order(O, built, ja, case):
+def test_planner_matches_literal_order(O, built, ja, case, split_mode):
     hap, n_ends, halves, hp, nc, n_reads, T = CASES[case]
     rng = np.random.default_rng(case)
     nh = len(hp) if hap else 1
