@@ -621,7 +621,7 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
         uint64_t reads_shard = 0, reads_lane_max = 0;
         for (uint64_t v : lane_reads) { reads_shard += v; reads_lane_max = std::max(reads_lane_max, v); }
         const uint64_t launch = std::min<uint64_t>(s.n_shard, 256ULL * JK_ILL_BLOCK);
-        const uint64_t pools = 4 * s.n_ends * std::min<uint64_t>(launch * (reads_lane_max / s.n_ends) * rec, a.max_batch_bytes ? a.max_batch_bytes : ~0ULL);
+        const uint64_t pools = 2 * s.n_ends * std::min<uint64_t>(launch * (reads_lane_max / s.n_ends) * rec, a.max_batch_bytes ? a.max_batch_bytes : ~0ULL);
         const uint64_t image = s.streaming ? 0 : (reads_shard / s.n_ends) * rec * s.n_ends;
         size_t free_b = 0, total_b = 0;
         JK_HIP(hipMemGetInfo(&free_b, &total_b));

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <deque>
 #include <numeric>
 #include <random>
@@ -109,11 +110,20 @@ struct GroupChain {
 // t * min(p, 1-p) >= 8 uses the distribution object (rejection algorithm, stateful normal deviate);
 // below that the waiting-time algorithm, restated: sum of -log(1 - u) / (t - x) until it exceeds -log(1 - p12).
 struct BinomDraw {
+    typedef std::binomial_distribution<uint64_t>::param_type Param;
     std::binomial_distribution<uint64_t> dist{1, 0.5};
+    // param_type's constructor (two lgammas, four logs, three exps: ~1 us) is a pure function of (t, p), and the lanes of
+    // a run ask for the same few hundred pairs over and over (same probabilities, read counts within a few sigma of each
+    // other): a small direct-mapped cache of constructed parameters
+    struct Slot { uint64_t t; double p; Param par; bool used; Slot() : t(0), p(0), par(1, 0.5), used(false) {} };
+    std::vector<Slot> cache{512};
     uint64_t operator()(HostPcg& eng, uint64_t t, double p) {
         const double p12 = p <= 0.5 ? p : 1.0 - p;
         if (static_cast<double>(t) * p12 >= 8) {
-            dist.param(std::binomial_distribution<uint64_t>::param_type(t, p));
+            uint64_t pb; std::memcpy(&pb, &p, 8);
+            Slot& sl = cache[(size_t)((t * 0x9E3779B97F4A7C15ULL) ^ (pb * 0xC2B2AE3D27D4EB4FULL)) >> 55];
+            if (!sl.used || sl.t != t || sl.p != p) { sl.par = Param(t, p); sl.t = t; sl.p = p; sl.used = true; }
+            dist.param(sl.par);
             return dist(eng);
         }
         const double q = -std::log(1 - p12);
