@@ -99,17 +99,13 @@ int jk_create_genome(uint64_t n_chroms, double len_mean, double len_sd, const do
         P.n_runs = run_first[n_chroms]; P.n_chroms = (uint32_t)n_chroms;
         const uint64_t grid = (P.n_runs + GENOME_BLOCK - 1) / GENOME_BLOCK;
         if (grid > 0x7fffffffULL) throw Error(JK_ERR_UNSUPPORTED, "genome too large for one launch");
-        hipEvent_t e0, e1;
-        JK_HIP(hipEventCreate(&e0)); JK_HIP(hipEventCreate(&e1));
-        JK_HIP(hipEventRecord(e0, nullptr));
+        EventPair ev;                  // (destroyed on every path out of here)
+        JK_HIP(hipEventRecord(ev.a, nullptr));
         hipLaunchKernelGGL(create_genome_kernel, dim3((uint32_t)grid), dim3(GENOME_BLOCK), 0, nullptr, P);
         JK_HIP(hipGetLastError());
-        JK_HIP(hipEventRecord(e1, nullptr));
+        JK_HIP(hipEventRecord(ev.b, nullptr));
         JK_HIP(hipDeviceSynchronize());
-        float t = 0;
-        JK_HIP(hipEventElapsedTime(&t, e0, e1));
-        G->ms = t;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        G->ms = ev.ms();
         *out = G.release();
     });
 }
@@ -306,9 +302,8 @@ static void fasta_pack_file(jk_genome& G, const HostText& text, const FastaPlan&
     P.iv_begin = d_ib.as<uint64_t>(); P.iv_end = d_ie.as<uint64_t>(); P.n_iv = (uint32_t)nc;
     P.strip_cr = strip_cr ? 1 : 0; P.upper = upper ? 1 : 0;
     P.block_cnt = d_cnt.as<uint64_t>(); P.block_off = d_off.as<uint64_t>(); P.iv_out = d_ivout.as<uint64_t>();
-    hipEvent_t e0, e1;
-    JK_HIP(hipEventCreate(&e0)); JK_HIP(hipEventCreate(&e1));
-    JK_HIP(hipEventRecord(e0, nullptr));
+    EventPair ev;
+    JK_HIP(hipEventRecord(ev.a, nullptr));
     hipLaunchKernelGGL(fasta_count_kernel, dim3((uint32_t)n_blocks), dim3(FASTA_THREADS), 0, nullptr, P);
     hipLaunchKernelGGL(scan_block_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, nullptr, d_cnt.as<uint64_t>(), d_off.as<uint64_t>(), d_sums.as<uint64_t>(), (uint32_t)n_blocks);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, nullptr, d_sums.as<uint64_t>(), nsb, d_base.as<uint64_t>());
@@ -322,12 +317,9 @@ static void fasta_pack_file(jk_genome& G, const HostText& text, const FastaPlan&
     P.out = out->as<uint8_t>();
     hipLaunchKernelGGL(fasta_pack_kernel, dim3((uint32_t)n_blocks), dim3(FASTA_THREADS), 0, nullptr, P);
     JK_HIP(hipGetLastError());
-    JK_HIP(hipEventRecord(e1, nullptr));
+    JK_HIP(hipEventRecord(ev.b, nullptr));
     JK_HIP(hipDeviceSynchronize());
-    float t = 0;
-    JK_HIP(hipEventElapsedTime(&t, e0, e1));
-    if (ms) *ms += t;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms) *ms += ev.ms();
     std::vector<uint64_t> ivout(nc);
     JK_HIP(hipMemcpy(ivout.data(), d_ivout.p, nc * 8, hipMemcpyDeviceToHost));
     std::vector<uint64_t> off(nc), len(nc);
