@@ -106,9 +106,10 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
             Q.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
             if (b >= ns) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - ns], 0));
             JK_HIP(hipEventRecord(s.events[ev++], s.stream));
-            const uint32_t pgrid = (B.n_lanes + 255) / 256;
-            if (s.hap) hipLaunchKernelGGL((pacbio_kernel<true>), dim3(pgrid), dim3(256), 0, s.stream, Q);
-            else hipLaunchKernelGGL((pacbio_kernel<false>), dim3(pgrid), dim3(256), 0, s.stream, Q);
+            const uint32_t pgrid = (B.n_lanes + PB_BLOCK - 1) / PB_BLOCK;
+            Q.xchg = s.d_pb_xchg.as<uint32_t>();
+            if (s.hap) hipLaunchKernelGGL((pacbio_kernel<true>), dim3(pgrid), dim3(PB_BLOCK), PB_LDS_BYTES, s.stream, Q);
+            else hipLaunchKernelGGL((pacbio_kernel<false>), dim3(pgrid), dim3(PB_BLOCK), PB_LDS_BYTES, s.stream, Q);
             JK_HIP(hipGetLastError());
             JK_HIP(hipEventRecord(s.events[ev++], s.stream));
             JK_HIP(hipEventRecord(s.gen_done[b], s.stream));

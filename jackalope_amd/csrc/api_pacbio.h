@@ -153,6 +153,9 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     P.g.n_chroms = s.n_chroms;
     P.ev = s.d_ev2.as<uint64_t>(); P.ev_words = s.ev_words;
     s.d_pb_hist.alloc((size_t)2 * PB_HIST * std::max<uint32_t>(max_lanes, 1) * 8);
+    s.d_pb_xchg.alloc((size_t)PB_XCHG_WORDS * align_up(std::max<uint32_t>(max_lanes, 1), PB_BLOCK) * 4);
+    JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pacbio_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PB_LDS_BYTES));
+    JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pacbio_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PB_LDS_BYTES));
     P.hist = s.d_pb_hist.as<uint64_t>();
     // Outside the reference's `read` string its behaviour is undefined; by default such a read ends the run
     // (JK_ERR_UNSUPPORTED).  Opt-in: treat the byte as NUL, which is what freshly allocated string capacity holds.

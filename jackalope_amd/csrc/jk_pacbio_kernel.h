@@ -52,6 +52,7 @@ struct PacbioKernelParams {
     uint64_t* lane_made;
     uint64_t* ev;                 // [ev_words][n_lanes] 2-bit event codes
     uint32_t ev_words;
+    uint32_t* xchg;               // [PB_XCHG_WORDS][n_lanes rounded up to the workgroup]: lane states on their way between threads
     uint64_t* hist;               // [2 * PB_HIST][n_lanes]: what earlier reads left in the reference's `read` buffer
     uint32_t undefined_as_nul;    // JK_PB_UNDEFINED_AS_NUL=1: a position outside that buffer reads as NUL instead of ending the run
     uint32_t* err;
@@ -101,7 +102,12 @@ __device__ __forceinline__ uint64_t cut_point(double c, bool* all) {
 // unconditionally and merely advance the write offset by 0, 1 or 2 (a deleted or absent byte is overwritten by the
 // next one), with no shifting or masking in registers.
 // ---------------------------------------------------------------------------------------------
-constexpr int PB_BLOCK = 256;
+#ifndef JK_PB_BLOCK
+#define JK_PB_BLOCK 256
+#endif
+constexpr int PB_BLOCK = JK_PB_BLOCK;  // lanes per workgroup = the pool the lanes of a wave are regrouped from, read by read
+constexpr uint32_t PB_XCHG_WORDS = 48; // 32-bit words of lane state that move with a lane (see the regrouping in pacbio_kernel)
+constexpr size_t PB_LDS_BYTES = (size_t)144 * PB_BLOCK + (size_t)4 * PB_BLOCK;   // stages + sort keys
 constexpr uint32_t PB_HIST = 16;      // depth of the per-lane history of buffer-covering reads (see pacbio_kernel)
 constexpr uint32_t PB_STAGE = 144;    // 128 + what one step of the word path can add beyond its flush threshold
 constexpr uint32_t PB_FLUSH_AT = 112; // wave-synchronised flush threshold of the per-position loops
@@ -154,37 +160,56 @@ __device__ __forceinline__ void ls_finish(LinStream& s) {
     for (uint32_t j = 0; j < s.off; j++) s.gp[j] = s.lds[j];
 }
 
+// Lanes are regrouped read by read.  A wave runs the per-position loops of its 64 lanes in lock-step, so it takes as
+// long as its longest read, and PacBio reads differ by thousands of positions (5-15 kb in BASELINE configs[4]: a third
+// of the issue slots went to lanes waiting for the longest read of their wave).  The lane is still the unit of the
+// computation -- its own pcg64, quotas, distribution states, output stream -- but which THREAD carries it is decided
+// anew for every read: once the read's length is known, the 1024 lanes of the workgroup are ranked by it, every thread
+// parks its lane's state (PB_XCHG_WORDS words, through a [word][lane] scratch in HBM, coalesced) in the slot of the
+// lane's rank and takes over the lane in its own slot, so that each wave gets 64 reads of nearly the same length (the
+// k-th wave the k-th 16th of the lengths).  Results do not depend on the grouping: no per-lane value is derived from
+// the thread index.
 template <bool HAP>
-__global__ void __launch_bounds__(PB_BLOCK, 4)       // 4 waves per SIMD -> at most 128 VGPRs
+__global__ void __launch_bounds__(PB_BLOCK, 1024 / PB_BLOCK)      // 16 waves per CU, 4 per SIMD -> at most 128 VGPRs
 pacbio_kernel(PacbioKernelParams P) {
-    __shared__ __align__(16) uint8_t stage[PB_STAGE * PB_BLOCK];
-    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= P.n_lanes) return;
+    extern __shared__ __align__(16) uint8_t pb_smem[];                 // PB_LDS_BYTES of dynamic LDS (more than the static limit)
+    uint8_t* const stage = pb_smem;                                    // [lane of the workgroup]: travels with the lane, not the thread
+    uint32_t* const s_key = reinterpret_cast<uint32_t*>(pb_smem + PB_STAGE * PB_BLOCK);
+    const uint32_t wg0 = blockIdx.x * blockDim.x;
+    uint32_t lane = wg0 + threadIdx.x;
+    bool valid = lane < P.n_lanes;
 
     LaneRng rng;
-    rng.e = jk_pcg_limbs(jk_pcg_seed(P.seeds + (size_t)lane * 8));
+    rng.e = jk_pcg_limbs(jk_pcg_seed(P.seeds + (size_t)(valid ? lane : 0) * 8));
     jk_gamma_state ln_st; ln_st.saved = 0.0; ln_st.saved_available = 0; ln_st.fail = 0;     // lognormal_distribution::_M_nd
     jk_gamma_state chi_st; chi_st.saved = 0.0; chi_st.saved_available = 0; chi_st.fail = 0;  // chi_squared -> gamma -> _M_nd
 
-    const uint64_t quota = P.lane_reads[lane];
+    uint64_t quota = valid ? P.lane_reads[lane] : 0;
     uint64_t made = 0, in_pool = 0;
     const uint32_t n_cells = HAP ? P.h.n_haps * P.g.n_chroms : P.g.n_chroms;
     uint32_t ci = 0;
-    uint64_t ccnt = n_cells ? P.chrom_reads[lane] : 0;
+    uint64_t ccnt = (n_cells && valid) ? P.chrom_reads[lane] : 0;
     uint32_t cur_hap = 0xffffffffu;
 
-    const uint32_t tile = lane >> 6;
-    const uint64_t tile_off = P.pool_off[tile];
-    const uint64_t lane_cap = (P.pool_off[tile + 1] - tile_off) >> 6;      // a multiple of 128 (host)
+    // what follows from the lane's identity (set again whenever the thread takes over another lane)
+    uint64_t lane_cap = 0;
+    uint64_t* evl = nullptr; uint64_t* hl = nullptr;
     LinStream o;
-    o.gp = P.pool + tile_off + (uint64_t)(lane & 63u) * lane_cap;           // this lane's contiguous region
-    o.lds = stage + threadIdx.x * PB_STAGE;
-    o.off = 0; o.pos = 0;
+    o.gp = nullptr; o.lds = stage; o.off = 0; o.pos = 0;
+    auto bind_lane = [&]() {
+        const uint32_t l = valid ? lane : wg0;
+        const uint32_t tile = l >> 6;
+        lane_cap = (P.pool_off[tile + 1] - P.pool_off[tile]) >> 6;          // a multiple of 128 (host)
+        evl = P.ev + l; hl = P.hist + l;
+        o.lds = stage + (l - wg0) * PB_STAGE;
+    };
+    bind_lane();
+    if (valid) o.gp = P.pool + P.pool_off[lane >> 6] + (uint64_t)(lane & 63u) * lane_cap;      // this lane's contiguous region
 
     uint32_t err = 0;
     const size_t ev_stride = (size_t)P.n_lanes;
-    uint64_t* const evl = P.ev + lane;
     const uint64_t max_pos = (uint64_t)P.ev_words * 32u;
+    const size_t xstride = (size_t)gridDim.x * PB_BLOCK;
 
     uint64_t L = 0, read_start = 0, chrom_len = 0;
     bool is_dup = false;
@@ -199,9 +224,14 @@ pacbio_kernel(PacbioKernelParams P) {
     // equals the string's size, and lies outside the string otherwise (undefined in the reference, refused here).
     uint32_t hdepth = 0;
     uint64_t buf_size = 0;            // size of that string: the longest window so far (position == size reads its NUL)
-    uint64_t* const hl = P.hist + lane;
     const size_t hstride = (size_t)P.n_lanes;
-    while (made < quota) {
+    for (;;) {
+        // a read = part A (cell, read length), regrouping of the workgroup's lanes by that length, part B (the rest).  A
+        // `break` inside a part leaves the part: the lane then has an error bit set or its quota met and takes no more turns.
+        const bool alive = valid && made < quota && err == 0;
+        if (!__syncthreads_or(alive ? 1 : 0)) break;
+        bool part_b = false;
+        if (alive) do {
         if (!is_dup) {
             // chromosome / cell.  Reference genome: first chromosome with a non-zero quota; the quota is never
             // decremented on this path (src/hts_pacbio.cpp:145-151).  Haplotypes: cursor search (:498-521).
@@ -238,6 +268,62 @@ pacbio_kernel(PacbioKernelParams P) {
             if (L >= chrom_len) L = chrom_len;
         }
         if (err) break;
+        part_b = true;
+        } while (0);
+
+        // ---- regroup: rank the workgroup's lanes by the length of the read they are about to make (idle lanes first)
+        {
+            const uint32_t key = part_b ? (uint32_t)(L < 0x7ffffffeULL ? L : 0x7ffffffeULL) + 1u : 0u;
+            s_key[threadIdx.x] = key;
+            __syncthreads();
+            uint32_t rank = 0;
+            const uint4* k4 = reinterpret_cast<const uint4*>(s_key);
+            for (uint32_t j = 0; j < PB_BLOCK / 4; j++) {
+                const uint4 v = k4[j];                  // (every lane of the wave reads the same address: a broadcast)
+                const uint32_t t0 = 4u * j;
+                rank += (v.x < key || (v.x == key && t0 < threadIdx.x)) ? 1u : 0u;
+                rank += (v.y < key || (v.y == key && t0 + 1u < threadIdx.x)) ? 1u : 0u;
+                rank += (v.z < key || (v.z == key && t0 + 2u < threadIdx.x)) ? 1u : 0u;
+                rank += (v.w < key || (v.w == key && t0 + 3u < threadIdx.x)) ? 1u : 0u;
+            }
+            // park this lane at its rank, take the lane parked at this thread's slot.  Slots are dealt to waves so that
+            // the waves sharing a SIMD get short and long reads alike (wave w of a workgroup sits on SIMD w % 4: with the
+            // plain order SIMD 3 would hold the longest reads of every pass and the CU would wait for it): the 64-lane
+            // rank groups go to the waves in a snake over the SIMDs -- groups s, 7 - s, 8 + s, 15 - s to SIMD s
+            const uint32_t wv = threadIdx.x >> 6, pass_i = wv >> 2, simd = wv & 3u;
+            const uint32_t grp = PB_BLOCK >= 512 ? 4u * pass_i + ((pass_i & 1u) ? 3u - simd : simd) : wv;
+            const uint32_t my_slot = grp * 64u + (threadIdx.x & 63u);
+            uint32_t* xp = P.xchg + wg0 + rank;
+            uint32_t k = 0;
+            auto put = [&](uint32_t v) { xp[(size_t)k * xstride] = v; k++; };
+            auto put64 = [&](uint64_t v) { put((uint32_t)v); put((uint32_t)(v >> 32)); };
+            put(lane); put((valid ? 1u : 0u) | (part_b ? 2u : 0u) | (is_dup ? 4u : 0u) | ((uint32_t)ln_st.saved_available << 3) | ((uint32_t)chi_st.saved_available << 4) |
+                           ((uint32_t)ln_st.fail << 5) | ((uint32_t)chi_st.fail << 6));
+            put(rng.e.s0); put(rng.e.s1); put(rng.e.s2); put(rng.e.s3); put64(rng.e.inc_lo); put64(rng.e.inc_hi);
+            put64(jk_d2u(ln_st.saved)); put64(jk_d2u(chi_st.saved));
+            put64(quota); put64(made); put64(in_pool); put(ci); put64(ccnt); put(cur_hap);
+            put64((uint64_t)(uintptr_t)o.gp); put(o.off); put64(o.pos); put(err);
+            put64(L); put64(read_start); put64(chrom_len); put(hdepth); put64(buf_size);
+            static_assert(PB_XCHG_WORDS >= 42, "lane state does not fit its exchange record");
+            __syncthreads();
+            const uint32_t* gp = P.xchg + wg0 + my_slot;
+            k = 0;
+            auto get = [&]() -> uint32_t { const uint32_t v = gp[(size_t)k * xstride]; k++; return v; };
+            auto get64 = [&]() -> uint64_t { const uint64_t a = get(); const uint64_t b = get(); return a | (b << 32); };
+            lane = get();
+            const uint32_t fl = get();
+            valid = fl & 1u; part_b = (fl >> 1) & 1u; is_dup = (fl >> 2) & 1u;
+            ln_st.saved_available = (fl >> 3) & 1u; chi_st.saved_available = (fl >> 4) & 1u; ln_st.fail = (fl >> 5) & 1u; chi_st.fail = (fl >> 6) & 1u;
+            rng.e.s0 = get(); rng.e.s1 = get(); rng.e.s2 = get(); rng.e.s3 = get(); rng.e.inc_lo = get64(); rng.e.inc_hi = get64();
+            ln_st.saved = jk_u2d(get64()); chi_st.saved = jk_u2d(get64());
+            quota = get64(); made = get64(); in_pool = get64(); ci = get(); ccnt = get64(); cur_hap = get();
+            o.gp = reinterpret_cast<uint8_t*>((uintptr_t)get64()); o.off = get(); o.pos = get64(); err = get();
+            L = get64(); read_start = get64(); chrom_len = get64(); hdepth = get(); buf_size = get64();
+            bind_lane();
+            __syncthreads();           // (the records are rewritten in the next round)
+        }
+
+        if (part_b) do {
         // ---- number of passes (src/hts_pacbio.h:149-205)
         const double Ld = (double)L;
         double n = P.cn[0] * (Ld < P.cn[2] ? Ld : P.cn[2]) + P.cn[1];
@@ -687,11 +773,14 @@ pacbio_kernel(PacbioKernelParams P) {
         const bool dup = P.dup_all || xd < P.th_dup;
         if (dup && made < quota && in_pool < P.pool_size) is_dup = true;
         else { is_dup = false; if (in_pool >= P.pool_size || made >= quota) in_pool = 0; }
+        } while (0);
     }
-    ls_finish(o);
-    P.lane_bytes[lane] = o.pos;
-    if (o.pos > lane_cap) err |= JK_KERR_POOL_OVERFLOW;
-    P.lane_made[lane] = made;
+    if (valid) {
+        ls_finish(o);
+        P.lane_bytes[lane] = o.pos;
+        if (o.pos > lane_cap) err |= JK_KERR_POOL_OVERFLOW;
+        P.lane_made[lane] = made;
+    }
     if (err) atomicOr(P.err, err);
 }
 
