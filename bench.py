@@ -350,7 +350,10 @@ def pacbio_main(a):
     mbp = a.genome_mbp if a.genome_mbp != 100.0 else 3000.0
     genome = ja.synthetic_genome([int(mbp * 1e6)], seed=3)
     n_reads = int(mbp * 1e6 * 20 / 10000) * world
-    lanes = (a.lanes if a.lanes != DEFAULT_LANES else (1 << 20)) * world
+    # 2^21 lanes per GPU: with ~3 reads per lane a launch of 2^18 lanes (one 256-lane workgroup slot per SIMD wave slot:
+    # 16 waves per CU) fits the 48 GB pool cap; at 2^20 lanes (6 reads each) a launch holds 196 k lanes, 12 waves per CU,
+    # and the latency-bound kernel runs at 20 instead of 23.5 M reads/s
+    lanes = (a.lanes if a.lanes != DEFAULT_LANES else (1 << 21)) * world
     lens = list(range(5000, 15001, 500))
     words = ja.seed_words(12345, 16 * lanes)
     sess = open_shard(lambda lo, hi, off: ja.pacbio(genome, None, n_reads, n_threads=lanes, seed_words=words, custom_read_lengths=lens,
