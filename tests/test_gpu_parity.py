@@ -200,10 +200,10 @@ def test_compressed_sinks(ja, O, tmp_path):
 def test_unsupported_inputs_fail_loudly(ja):
     g = ja.synthetic_genome([10_000], seed=16)
     words = ja.seed_words(1, 64)
-    # a lane's position in its pool is 32-bit: 7 M pairs on one lane would be 4.6 GiB per read end.  Refused before any
+    # a lane's position in its pool is 32-bit: 14 M pairs on one lane would be 4.6 GiB per read end.  Refused before any
     # allocation, with the remedy in the message (R users meet this with n_threads = 1 and a large n_reads).
     with pytest.raises(ja.JackalopeHipError, match="raise n_threads") as e:
-        ja.illumina(g, None, 14_000_000, 150, True, n_threads=1, seed_words=words, _session=True)
+        ja.illumina(g, None, 28_000_000, 150, True, n_threads=1, seed_words=words, _session=True)
     assert e.value.code == 2
     # pools + image beyond device memory: the sizes are named instead of a bare hipMalloc failure (64 lanes x 6 M pairs:
     # every lane stays below 4 GiB, the tile's pools would need ~260 GB per read end)
