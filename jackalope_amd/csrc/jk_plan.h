@@ -302,7 +302,28 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
     auto keep_hr = [&](uint64_t t, const uint64_t* hr) {
         if (t >= lane_begin && t < lane_end) for (uint64_t h = 0; h < nh; h++) hr_own[(t - lane_begin) * nh + h] = (uint32_t)hr[h];
     };
-    const uint16_t spec = (uint16_t)(1 + 2 * nh);
+    // speculation: every haplotype that can get reads gets enough for both of its seed draws.  The expected number of
+    // lanes for which that is wrong decides whether the speculative passes are tried at all.
+    uint16_t spec = 1;
+    double expect_bad = 0;
+    {
+        const GroupChain& H = M.hap_chain;
+        const uint64_t n_min = n_active ? pairs_of(n_active - 1) : 0;
+        double rest = 1.0;
+        for (size_t g = 0; g < H.G; g++) {
+            double pg = rest;
+            if (g + 1 < H.G) {
+                if (H.kind[g] == 0) { pg = rest * H.p[g]; rest *= 1.0 - H.p[g]; }
+                else if (H.kind[g] == 2) { pg = rest; rest = 0.0; }
+                else pg = 0.0;
+            }
+            if (pg <= 0.0) continue;
+            spec += 2;
+            double miss = std::pow(1.0 - pg, (double)n_min);
+            if (M.maker_halves && n_min > 0 && pg < 1.0) miss += (double)n_min * pg * std::pow(1.0 - pg, (double)(n_min - 1));
+            expect_bad += miss * (double)n_active;
+        }
+    }
     for (uint64_t i = 0; i < R; i++) need[i] = pairs_of(first + i) > 0 ? spec : 0;
     const uint64_t start = offset_given ? offset_words : after_mt;
     auto rebuild = [&](uint64_t from) {                // off[i] for i > from, from need[]
@@ -314,26 +335,93 @@ inline LanePlan plan_lane_quotas(const QuotaModel& M, const std::vector<uint64_t
     // fix-point: compute every lane's real need at its current offset; a lane whose need differs moves all later
     // offsets.  Lanes before the first difference are final, so each pass makes progress; the usual case is one pass.
     uint64_t stable = 0;                               // lanes [0, stable) are final
-    bool go_sequential = false;
+    bool go_sequential = expect_bad > 4.0;
     for (int pass = 0; stable < R; pass++) {
         if (pass >= 6 || go_sequential) {
             // few reads per lane and haplotype (a haplotype without reads is then common): every such lane moves all
-            // later offsets and a parallel pass only gets as far as the first of them -- the chain off[t+1] = off[t] +
-            // need(t, words at off[t]) is walked on one thread (0.7 us per lane)
+            // later offsets and a parallel pass only gets as far as the first of them.  The chain off[t+1] = off[t] +
+            // need(n_t, words at off[t]) is a walk over the 8-word slots of the seed array whose step depends on the
+            // slot and on n_t only -- and n_t takes two values (split_int: q+1 on the first lanes, q on the rest).  So
+            // the slot space is cut into ranges, each walked on its own thread with the n its lanes are expected to
+            // have; the one sequential walk that follows then finds nearly every slot it lands on already evaluated
+            // and evaluates the others itself (around the q+1 -> q change, past the estimated end).
             BinomDraw bd;
             std::vector<uint64_t> hr(nh);
-            for (uint64_t i = stable; i < R; i++) {
-                const uint64_t n = pairs_of(first + i);
-                uint16_t nd = 0;
-                if (n > 0) {
-                    std::fill(hr.begin(), hr.end(), (uint64_t)0);
-                    split_with_chain(n, M.hap_chain, words_at(off[i]), bd, [&](size_t h, uint64_t v) { hr[h] = v; });
-                    nd = (uint16_t)(1 + words_after_hap_split(M, hr.data()) / 8);
-                    keep_hr(first + i, hr.data());
-                }
-                need[i] = nd;
-                off[i + 1] = off[i] + 8ull * nd;
+            auto need_of = [&](BinomDraw& d, std::vector<uint64_t>& h, uint64_t n, uint64_t word_off) -> uint16_t {
+                std::fill(h.begin(), h.end(), (uint64_t)0);
+                split_with_chain(n, M.hap_chain, words_at(word_off), d, [&](size_t k, uint64_t v) { h[k] = v; });
+                return (uint16_t)(1 + words_after_hap_split(M, h.data()) / 8);
+            };
+            const uint64_t act = n_active > first ? std::min(R, n_active - first) : 0;      // lanes [0, act) of the range have reads
+            const uint64_t i0 = stable;
+            uint64_t i = i0;
+            const uint64_t n_sample = std::min<uint64_t>(act > i ? act - i : 0, 4096);    // mean step, from the first lanes
+            for (const uint64_t e = i + n_sample; i < e; i++) {
+                need[i] = need_of(bd, hr, pairs_of(first + i), off[i]);
+                off[i + 1] = off[i] + 8ull * need[i];
             }
+            if (i < act) {
+                const double mean = std::max(1.0, double(off[i] - off[i0]) / 8.0 / double(n_sample));
+                const uint64_t w0 = off[i];                                               // slot 0
+                const uint64_t nA = pairs_of(first + i), nB = pairs_of(first + act - 1);
+                uint64_t isw = i;                                                         // first lane with nB reads
+                if (nA != nB) { uint64_t lo = i, hi = act - 1; while (lo < hi) { uint64_t m = (lo + hi) / 2; if (pairs_of(first + m) == nB) hi = m; else lo = m + 1; } isw = lo; }
+                else isw = i;
+                const uint64_t RANGE = 16384;
+                uint64_t n_slots = (uint64_t)(double(act - i) * mean * 1.02) + 1024;
+                if (w0 < NW) n_slots = std::min(n_slots, (NW - w0) / 8); else n_slots = 0;
+                const uint64_t n_ranges = (n_slots + RANGE - 1) / RANGE;
+                std::vector<uint16_t> need_at(n_slots, 0);                               // 0: not evaluated
+                std::vector<uint8_t> range_is_B(n_ranges, 0);
+                std::vector<uint64_t> exit_slot(n_ranges, 0);                            // where range r's walk enters range r + 1
+                for (uint64_t r = 0; r < n_ranges; r++) range_is_B[r] = nA == nB || i + (uint64_t)(double(r * RANGE) / mean) >= isw;
+                // walk 1: every range from its first slot.  Walk 2: every range again from the slot its predecessor's
+                // walk left at, until it lands on a slot of walk 1 (with steps of mostly 1+2*n_haps slots two walks need
+                // some tens of lanes to fall into step) -- after which the chain from slot 0 is evaluated throughout,
+                // unless some range's two walks never met.
+                for (int walk = 0; walk < 2; walk++)
+                    parallel_for(n_ranges, 1, [&](size_t a, size_t b, unsigned) {
+                        BinomDraw d;
+                        std::vector<uint64_t> h(nh);
+                        for (size_t r = a; r < b; r++) {
+                            if (walk == 1 && r == 0) continue;
+                            const uint64_t end = std::min(n_slots, (r + 1) * RANGE);
+                            uint64_t sl = walk == 0 ? r * RANGE : exit_slot[r - 1];
+                            while (sl < end && (walk == 0 || need_at[sl] == 0)) {
+                                const uint16_t nd = need_of(d, h, range_is_B[r] ? nB : nA, w0 + 8 * sl);
+                                need_at[sl] = nd;
+                                sl += nd;
+                            }
+                            if (walk == 0) exit_slot[r] = sl;
+                        }
+                    });
+                uint64_t sl = 0, n_own_eval = 0;
+                const uint64_t i_walk = i;
+                for (; i < act; i++) {
+                    const uint64_t n = pairs_of(first + i);
+                    uint16_t nd = 0;
+                    if (sl < n_slots && need_at[sl] != 0 && (range_is_B[sl / RANGE] ? nB : nA) == n) nd = need_at[sl];
+                    else { nd = need_of(bd, hr, n, off[i]); n_own_eval++; }
+                    need[i] = nd;
+                    off[i + 1] = off[i] + 8ull * nd;
+                    sl += nd;
+                }
+                if (tm.on) std::fprintf(stderr, "[jk timing]   plan: slot walk over %llu lanes in %llu ranges, %llu evaluated by the walk itself\n",
+                                        (unsigned long long)(act - i_walk), (unsigned long long)n_ranges, (unsigned long long)n_own_eval);
+            }
+            for (; i < R; i++) { need[i] = 0; off[i + 1] = off[i]; }
+            // the hap-level split of this shard's lanes, at their final offsets
+            const uint64_t own_lo = std::max(first + i0, lane_begin), own_hi = std::min(first + act, lane_end);
+            if (own_hi > own_lo)
+                parallel_for(own_hi - own_lo, 2048, [&](size_t a, size_t b, unsigned) {
+                    BinomDraw d;
+                    std::vector<uint64_t> h(nh);
+                    for (size_t k = a; k < b; k++) {
+                        const uint64_t t = own_lo + k;
+                        need_of(d, h, pairs_of(t), off[t - first]);
+                        keep_hr(t, h.data());
+                    }
+                });
             stable = R;
             break;
         }

@@ -139,6 +139,33 @@ def test_planner_matches_literal_order(O, built, ja, case, split_mode):
         assert (s5 == s0[a:b]).all() and (q5 == q0[:, a:b]).all() and w5 == [total, int(begins[a]), int(begins[b])]
 
 
+@pytest.mark.parametrize("threads", ["1", "7"])
+def test_planner_few_reads_per_haplotype_many_lanes(built, ja, threads, monkeypatch):
+    """configs[3]'s shape (41 pairs per lane over 8 haplotypes: a haplotype without reads is common, so a lane's first
+    seed word cannot be speculated) at enough lanes that the planner's slot-range walk runs (csrc/jk_plan.h: ranges of
+    4096 seed slots walked in parallel, then stitched by one sequential walk), with the q+1 -> q change of split_int in
+    the middle.  Against the sequential callback path, which test_planner_matches_literal_order ties to the oracle."""
+    monkeypatch.setenv("JK_HOST_THREADS", threads)
+    T, nh, nc = 30_000, 8, 5
+    n_reads = 2 * (41 * T + 12_345)
+    chrom_probs = np.random.default_rng(9).integers(1000, 200_000, size=(nh, nc)).astype(np.float64)
+    words = ja.seed_words(77, 8 * T * (3 + 2 * nh) + 64)
+    hp = [1.0] * nh
+    s0, q0, w0 = planner(True, 2, True, hp, chrom_probs, n_reads, T, words, callback=True)
+    s1, q1, w1 = planner(True, 2, True, hp, chrom_probs, n_reads, T, words)
+    assert (s1 == s0).all() and (q1 == q0).all() and w1[0] == w0[0]
+    assert int(q1.sum()) == n_reads
+    a, b = 11_000, 23_456                                   # a shard across the change, offsets derived and handed in
+    s2, q2, w2 = planner(True, 2, True, hp, chrom_probs, n_reads, T, words, a, b)
+    assert (s2 == s0[a:b]).all() and (q2 == q0[:, a:b]).all() and w2[0] == w0[0]
+    s3, q3, w3 = planner(True, 2, True, hp, chrom_probs, n_reads, T, words, a, b, offset=w2[1])
+    assert (q3 == q0[:, a:b]).all() and w3[1:] == w2[1:]
+    # too few seed words: found after the walk, reported as such
+    with pytest.raises(_abi.JackalopeHipError) as e:
+        planner(True, 2, True, hp, chrom_probs, n_reads, T, words[:8 * T * 9])
+    assert e.value.code == _abi.JK_ERR_SEEDS
+
+
 def test_planner_seed_exhaustion(O, built, ja):
     words = ja.seed_words(5, 8 * 50 + 8 * 10)
     with pytest.raises(_abi.JackalopeHipError) as e:
