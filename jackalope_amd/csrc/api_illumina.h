@@ -287,6 +287,28 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     return max_lanes;
 }
 
+// The 2-bit copy of the (final) sequence buffer and its flags: GenomeDev::packed.  Made with JK_PACKED_REF=1 only: the
+// generator is bound by instruction issue, not by the reference loads, and with the copy it is 2-5 % SLOWER at every genome
+// size tried (100 Mbp / 1 Gbp / 3 Gbp: 702 / 700 / 671 against 736 / 718 / 709 M pairs/s, tools/packed_probe.sh; it fetches
+// a quarter of the cache lines) -- so the byte path stays the default and this one stays tested.
+static void pack_reference(jk_session& s) {
+    if (s.d_packed.p) return;
+    const char* e = std::getenv("JK_PACKED_REF");
+    if (!e || std::atoi(e) == 0) return;
+    PhaseTimer pt("packed reference");
+    const uint64_t n = s.d_seq.n;
+    const uint64_t n_threads = (n + 15) / 16, n_waves = (n_threads + 63) / 64;
+    s.d_packed.alloc(n_waves * 256 + 64);
+    s.d_nflags.alloc(n_waves * 2 + 64);
+    JK_HIP(hipMemset(s.d_nflags.p, 0xff, s.d_nflags.n));
+    const uint64_t blocks = (n_threads + 255) / 256;
+    if (blocks > 0x7fffffffULL) { s.d_packed.release(); s.d_nflags.release(); return; }
+    hipLaunchKernelGGL(pack_reference_kernel, dim3((uint32_t)blocks), dim3(256), 0, 0, s.d_seq.as<uint8_t>(), n,
+                       s.d_packed.as<uint32_t>(), s.d_nflags.as<uint16_t>());
+    JK_HIP(hipGetLastError());
+    JK_HIP(hipDeviceSynchronize());
+}
+
 static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const LanePlan& lp, const QuotaModel& Q, uint64_t rec_max) {
     const std::vector<uint64_t>& lane_reads = lp.lane_reads;
     // A batch is one generator launch.  Default: 2^18 lanes = one 1024-thread workgroup on each of the
@@ -319,11 +341,16 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     s.d_evw.alloc(2 * s.evw_set * 8);
 
     s.lds_bytes = packed.tab.size() * 4;        // dynamic LDS; the kernel keeps mm2 (2 KB) in static LDS on top
-    // haplotype runs add the per-lane segment table (JK_HAP_SEGS segments x 12 bytes x 1024 lanes) after the tables
-    const size_t seg_bytes = (s.hap && !s.hap_materialised) ? (size_t)JK_HAP_SEGS * 12 * JK_ILL_BLOCK : 0;
-    s.lds_tables = s.lds_bytes + seg_bytes <= 156 * 1024;
+    // after the tables: haplotype runs served from the mutation tables add the per-lane segment table (JK_HAP_SEGS segments
+    // x 12 bytes x 1024 lanes); every other run the 2 KB expansion table of the packed reference
+    const bool seg_run = s.hap && !s.hap_materialised;
+    const size_t seg_bytes = seg_run ? (size_t)JK_HAP_SEGS * 12 * JK_ILL_BLOCK : 0;
+    const size_t lut_bytes = seg_run ? 0 : 2048;
+    s.lds_tables = s.lds_bytes + seg_bytes + lut_bytes <= 156 * 1024;
     s.lds_seg_off = s.lds_tables ? (uint32_t)align_up(s.lds_bytes, 16) : 0;
-    s.lds_launch = (s.lds_tables ? align_up(s.lds_bytes, 16) : 0) + seg_bytes;
+    s.lds_lut_off = s.lds_seg_off;
+    s.lds_launch = (s.lds_tables ? align_up(s.lds_bytes, 16) : 0) + seg_bytes + lut_bytes;
+    if (!seg_run) pack_reference(s);
 
     IlluminaKernelParams& P = s.kp;
     P.g.seq = s.d_seq.as<uint8_t>();
@@ -332,12 +359,15 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     P.g.hdr_blob = s.d_hdr_blob.as<uint8_t>();
     P.g.hdr_off = s.d_hdr_off.as<uint32_t>();
     P.g.n_chroms = s.n_chroms;
+    P.g.packed = s.d_packed.p ? s.d_packed.as<uint8_t>() : nullptr;
+    P.g.nflags = s.d_nflags.p ? s.d_nflags.as<uint8_t>() : nullptr;
     P.evw = s.d_evw.as<uint64_t>();
     P.err = s.d_err.as<uint32_t>();
     P.tab = s.d_tab.as<uint32_t>(); P.mm2 = s.d_mm2.as<uint64_t>();
     P.n_info = (uint32_t)s.tables.info.size(); P.n_entries = (uint32_t)s.tables.thresh.size();
 
     P.lds_seg_off = s.lds_seg_off;
+    P.lds_lut_off = s.lds_lut_off;
     {
         const int lb = (int)s.lds_launch;
         auto allow = [&](const void* k) { JK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lb)); };
@@ -348,6 +378,8 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
             allow(JK_K(true, 1, true, false)); allow(JK_K(true, 2, true, false));
         } else if (lb) {
             allow(JK_K(false, 1, true, true)); allow(JK_K(false, 2, true, true));
+            allow(JK_K(false, 1, true, false)); allow(JK_K(false, 2, true, false));
+            allow(JK_K(false, 1, false, false)); allow(JK_K(false, 2, false, false));
         }
 #undef JK_K
     }

@@ -162,8 +162,8 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
             else            { if (s.n_ends == 2) JK_LAUNCH(true, 2, false, false, s.lds_launch); else JK_LAUNCH(true, 1, false, false, s.lds_launch); }
         } else {
             if (seg)        { if (s.n_ends == 2) JK_LAUNCH(false, 2, true, true, s.lds_launch); else JK_LAUNCH(false, 1, true, true, s.lds_launch); }
-            else if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(false, 2, true, false, 0); else JK_LAUNCH(false, 1, true, false, 0); }
-            else            { if (s.n_ends == 2) JK_LAUNCH(false, 2, false, false, 0); else JK_LAUNCH(false, 1, false, false, 0); }
+            else if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(false, 2, true, false, s.lds_launch); else JK_LAUNCH(false, 1, true, false, s.lds_launch); }
+            else            { if (s.n_ends == 2) JK_LAUNCH(false, 2, false, false, s.lds_launch); else JK_LAUNCH(false, 1, false, false, s.lds_launch); }
         }
 #undef JK_LAUNCH
         JK_HIP(hipGetLastError());

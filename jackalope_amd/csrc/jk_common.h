@@ -32,7 +32,13 @@ struct DevBuf {
     void alloc(size_t bytes) {
         release();
         if (bytes == 0) bytes = 16;
+        // (JK_TIMING: large allocations are timed on their own -- the driver clears VRAM it hands out that is not
+        // known to be clean, at ~45 GB/s, so a run that needs more than the clean part of HBM waits seconds here:
+        // tools/malloc_probe.hip)
+        const bool timed = bytes >= (1ull << 30) && std::getenv("JK_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         JK_HIP(hipMalloc(&p, bytes));
+        if (timed) std::fprintf(stderr, "[jk timing]   hipMalloc of %6.1f GB      %8.1f ms\n", bytes / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         n = bytes;
     }
     template <typename T> T* as() const { return static_cast<T*>(p); }

@@ -50,6 +50,12 @@ struct GenomeDev {
     const uint8_t* hdr_blob;     // "@<genome>-<chrom>-" per chromosome
     const uint32_t* hdr_off;     // [n_chroms + 1]
     uint32_t n_chroms;
+    // Illumina, optional (null: bytes only): the same bases at 2 bits each -- base i in bits 2*(i & 3) of packed[i >> 2],
+    // code as in seq -- and one flag bit per 64 bases, bit (i >> 6) & 7 of nflags[i >> 9], set when the 64 hold a byte that
+    // is not T, C, A or G (pack_reference_kernel).  A read end whose source window touches no flagged block takes its
+    // 8-base blocks from `packed` (one 4-byte load per block, a quarter of the cache lines); any other reads `seq`.
+    const uint8_t* packed;
+    const uint8_t* nflags;
 };
 
 // Haplotypes: the mutation tables of all (haplotype, chromosome) cells, cell = hap * n_chroms + chrom
@@ -113,6 +119,7 @@ struct IlluminaKernelParams {
     const uint32_t* tab; const uint64_t* mm2;
     uint32_t n_info, n_entries;
     uint32_t lds_seg_off;                                  // HAP: byte offset of the per-lane segment table in LDS
+    uint32_t lds_lut_off;                                  // packed reference: byte offset of the 512-entry expansion table in LDS
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -152,6 +159,19 @@ __device__ __forceinline__ void os_flush(OutStream& s, uint8_t* col) {
     const uint32_t cnt = s.pos & 3u;
     for (uint32_t j = 0; j < cnt; j++) wp[j] = (uint8_t)(s.acc >> (8u * j));
     s.acc = 0;
+}
+
+// Global-memory byte pointer that stays one through an asm barrier (a pointer that went through `asm("" : "+s"(p))` is a
+// generic one to the compiler otherwise: flat_load, which also counts as an LDS access, so every wait for an LDS read
+// would wait for the chunk prefetch as well), and unaligned 4- and 8-byte loads from it.
+typedef const __attribute__((address_space(1))) uint8_t* gbytes_t;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned_t;
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned_t;
+__device__ __forceinline__ uint32_t gload8(gbytes_t p) { return *p; }
+__device__ __forceinline__ uint32_t gload32(gbytes_t p) { return *reinterpret_cast<const __attribute__((address_space(1))) u32_unaligned_t*>(p); }
+__device__ __forceinline__ void gload64(gbytes_t p, uint32_t* v) {
+    const uint64_t x = *reinterpret_cast<const __attribute__((address_space(1))) u64_unaligned_t*>(p);
+    v[0] = (uint32_t)x; v[1] = (uint32_t)(x >> 32);
 }
 
 struct LaneRng {
@@ -347,6 +367,16 @@ illumina_kernel(IlluminaKernelParams P) {
     } else {
         T.tab = reinterpret_cast<const uint8_t*>(P.tab);
     }
+    // packed reference: 8 bits (4 bases, ascending source order) -> the 4 code bytes in read order; entries 256..511 for
+    // the reverse strand (descending source order, complemented: code ^ 2)
+    uint32_t* const s_lut = reinterpret_cast<uint32_t*>(smem + P.lds_lut_off);
+    if (!SEG && P.g.packed) {
+        for (uint32_t e = threadIdx.x; e < 512u; e += blockDim.x) {
+            const uint32_t a = e & 3u, b = (e >> 2) & 3u, c = (e >> 4) & 3u, d = (e >> 6) & 3u;
+            s_lut[e] = e < 256u ? (a | (b << 8) | (c << 16) | (d << 24))
+                                : ((d ^ 2u) | ((c ^ 2u) << 8) | ((b ^ 2u) << 16) | ((a ^ 2u) << 24));
+        }
+    }
     __syncthreads();
 
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
@@ -483,9 +513,11 @@ illumina_kernel(IlluminaKernelParams P) {
                     n_uni = __builtin_amdgcn_readlane(steps, (int)__builtin_ctzll(less));
                 uint32_t k = 0; bool hit = false;
                 uint64_t x = 0;
+                // (the ballot of the compare alone is the compare's own mask; with `nm ||` inside it the compiler goes
+                // through a VGPR: two more VALU instructions per draw)
                 while (k < n_uni) {
                     x = rng(); k++;
-                    if (__builtin_amdgcn_ballot_w64(nm || x < thm) != 0) { hit = true; break; }
+                    if (nm || __builtin_amdgcn_ballot_w64(x < thm) != 0) { hit = true; break; }
                 }
                 if (hit && (nm || x < thm)) { frag_pos += k - 1; len_now += k - 1; indel_event(x); frag_pos++; }
                 else { frag_pos += k; len_now += k; }
@@ -623,7 +655,10 @@ illumina_kernel(IlluminaKernelParams P) {
             //    with compile-time shifts;
             //  * single bases, the general path (barcodes, indels, 'N', segment changes, uneven read lengths), until
             //    the output position is a multiple of 4 again and no lane needs it.
-            const uint8_t* const gseq = P.g.seq;
+            // (the pointer as a scalar pair of its own: left as a member of the kernel-argument block, every chunk load
+            // restores the block's whole 8-register tuple from its spill lanes -- v_readlane is a VALU instruction)
+            gbytes_t gseq = (gbytes_t)P.g.seq;
+            asm volatile("" : "+s"(gseq));
             const uint8_t* const bcode = HAP ? P.h.bc_blob + (size_t)cur_hap * JK_MAX_BARCODE : P.barcode;
             uint64_t A = 0;
             // HAP: the read is served segment by segment (reference runs and mutation bytes);
@@ -676,9 +711,24 @@ illumina_kernel(IlluminaKernelParams P) {
             } else {
                 A = P.g.chrom_off[ci] + (reverse ? start + sp - 1 : start - bc);
             }
+            // packed reference: may this read end take its 8-base blocks from the 2-bit copy?  (Its source window
+            // [lo, lo + cspace) must not touch a flagged 64-base block, and the copy's byte offsets are kept in 32 bits.)
+            bool use_bytes = true;
+            uint32_t pk_off = 0, pk_sh = 0;     // byte offset of the current block's dword in `packed`; bit position of its first-quad byte
+            gbytes_t pk = (gbytes_t)P.g.packed;
+            asm volatile("" : "+s"(pk));
+            if (!SEG && P.g.packed != nullptr && sp > bc) {
+                const uint64_t lo = P.g.chrom_off[ci] + start, last = lo + cspace - 1;
+                const uint64_t b0 = lo >> 6;
+                const uint32_t nb = (uint32_t)((last >> 6) - b0) + 1u;
+                uint32_t fw;
+                __builtin_memcpy(&fw, P.g.nflags + (b0 >> 3), 4);
+                const uint32_t bits = (fw >> ((uint32_t)b0 & 7u)) & ((1u << (nb < 25u ? nb : 25u)) - 1u);
+                use_bytes = bits != 0u || nb > 25u || (last >> 2) >= 0xffffff00ULL;
+            }
             auto src_byte = [&](uint32_t pp) -> uint32_t {     // general path: one source base (pp >= bc)
                 if (SEG) { while (pp >= seg_end_pp) seg_enter(pp); }
-                uint32_t c = gseq[reverse ? A - pp : A + pp];
+                uint32_t c = gload8(gseq + (reverse ? A - pp : A + pp));
                 if (reverse) c ^= ((~c) >> 1) & 2u;                 // codes 0..3: ^2 (T<->A, C<->G); others stay non-TCAG
                 return c;
             };
@@ -771,15 +821,38 @@ illumina_kernel(IlluminaKernelParams P) {
                 uint32_t wlo = 0, whi = 0, nmlo = 0, nmhi = 0;
                 bool seg_moved = false, any_n = false;      // any_n: some lane's chunk holds a byte that is not TCAG (wave-uniform)
                 if (nquads == 2u) {
-                    uint32_t v[2];
-                    if (have_pf) { v[0] = pf[0]; v[1] = pf[1]; }
-                    else __builtin_memcpy(v, gseq + (reverse ? A - pp - 7u : A + pp), 8);
-                    __builtin_memcpy(pf, gseq + (reverse ? A - pp - 15u : A + pp + 8u), 8);      // (stays inside the buffer's padding)
+                    if (!SEG && !use_bytes) {
+                        // 16 bits of the 2-bit copy: the block's 8 source bases in ascending order, from bit pk_sh' of the
+                        // dword at pk_off (2 bytes further per block, so the shift stays what it is); each half goes through
+                        // the LDS table into read order.  The next block's dword is requested now, like the byte chunk below.
+                        uint32_t v;
+                        if (have_pf) v = pf[0];
+                        else {
+                            const uint64_t p0 = reverse ? A - pp - 7u : A + pp;        // lowest source base of the block
+                            pk_off = (uint32_t)(p0 >> 2);
+                            pk_sh = 2u * ((uint32_t)p0 & 3u) + (reverse ? 8u : 0u);
+                            v = gload32(pk + pk_off);
+                        }
+                        const uint32_t* lut = s_lut + (reverse ? 256u : 0u);
+                        const uint32_t q0 = __builtin_amdgcn_ubfe(v, pk_sh, 8u), q1 = __builtin_amdgcn_ubfe(v, reverse ? pk_sh - 8u : pk_sh + 8u, 8u);
+                        pk_off += reverse ? 0xfffffffeu : 2u;
+                        pf[0] = gload32(pk + pk_off);                                  // (stays inside the copy's padding)
+                        wlo = lut[q0];
+                        whi = lut[q1];
+                    }
+                    bool n_here = false;
+                    if (SEG || use_bytes) {
+                        uint32_t v[2];
+                        if (have_pf) { v[0] = pf[0]; v[1] = pf[1]; }
+                        else gload64(gseq + (reverse ? A - pp - 7u : A + pp), v);
+                        gload64(gseq + (reverse ? A - pp - 15u : A + pp + 8u), pf);      // (stays inside the buffer's padding)
+                        const uint32_t rlo = __builtin_amdgcn_perm(v[1], v[0], rsel), rhi = __builtin_amdgcn_perm(v[1], v[0], rsel ^ 0x04040404u);
+                        wlo = rlo ^ rcm; whi = rhi ^ rcm;
+                        n_here = ((v[0] | v[1]) & 0xfcfcfcfcu) != 0;
+                        nmlo = rlo & 0xfcfcfcfcu; nmhi = rhi & 0xfcfcfcfcu;       // non-zero bytes: positions that are not TCAG
+                    }
                     have_pf = true;
-                    const uint32_t rlo = __builtin_amdgcn_perm(v[1], v[0], rsel), rhi = __builtin_amdgcn_perm(v[1], v[0], rsel ^ 0x04040404u);
-                    wlo = rlo ^ rcm; whi = rhi ^ rcm;
-                    any_n = __builtin_amdgcn_ballot_w64(((v[0] | v[1]) & 0xfcfcfcfcu) != 0) != 0;
-                    if (any_n) { nmlo = rlo & 0xfcfcfcfcu; nmhi = rhi & 0xfcfcfcfcu; }       // non-zero bytes: positions that are not TCAG
+                    any_n = __builtin_amdgcn_ballot_w64(n_here) != 0;
                 } else have_pf = false;
                 if (nquads == 1u) {
                     if (SEG && gather_gear) {
@@ -787,7 +860,7 @@ illumina_kernel(IlluminaKernelParams P) {
                         uint32_t w, bad;
                         if (room >= 4u) {
                             uint32_t v;
-                            __builtin_memcpy(&v, gseq + (reverse ? A - pp - 3u : A + pp), 4);
+                            v = gload32(gseq + (reverse ? A - pp - 3u : A + pp));
                             w = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u) ^ rcm; bad = v & 0xfcfcfcfcu;
                         } else {
                             // one 4-byte load per segment the four positions touch: each is read as if all four lay in
@@ -797,7 +870,7 @@ illumina_kernel(IlluminaKernelParams P) {
                             while (filled < 4u) {
                                 while (pp + filled >= seg_end_pp) seg_enter(pp + filled);
                                 uint32_t v;
-                                __builtin_memcpy(&v, gseq + (reverse ? A - pp - 3u : A + pp), 4);
+                                v = gload32(gseq + (reverse ? A - pp - 3u : A + pp));
                                 const uint32_t left = seg_end_pp - (pp + filled), n = left < 4u - filled ? left : 4u - filled;
                                 const uint32_t mask = (n >= 4u ? 0xffffffffu : ((1u << (8u * n)) - 1u)) << (8u * filled);
                                 w |= (__builtin_amdgcn_perm(0u, v, rsel & 0x03030303u) ^ rcm) & mask;
@@ -810,7 +883,7 @@ illumina_kernel(IlluminaKernelParams P) {
                         else { A = A0; seg_end_pp = se0; seg_state = st0; seg_moved = false; nquads = 0; }    // not TCAG somewhere: the general path redoes it
                     } else {
                         uint32_t v;
-                        __builtin_memcpy(&v, gseq + (reverse ? A - pp - 3u : A + pp), 4);
+                        v = gload32(gseq + (reverse ? A - pp - 3u : A + pp));
                         const uint32_t rlo = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u);
                         wlo = rlo ^ rcm;
                         any_n = __builtin_amdgcn_ballot_w64((v & 0xfcfcfcfcu) != 0) != 0;
@@ -967,6 +1040,37 @@ __global__ void encode_bases_kernel(uint8_t* seq, uint64_t n, uint32_t* bad) {
         const uint8_t c = seq[k];
         if (c >= JK_LOW_BYTE_BASE) *bad = 1;
         seq[k] = c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : c == 'G' ? 3 : (c < 4 ? (uint8_t)(JK_LOW_BYTE_BASE + c) : c);
+    }
+}
+
+// The 2-bit copy of an encoded buffer and its "not only TCAG" flags (GenomeDev::packed / nflags).  One thread per 16
+// bases (one output dword), one wave per 1024: 64 bases = 4 neighbouring lanes, so a wave's 16 flag bits come out of
+// one ballot.  n is the buffer's length; bytes past it count as flagged.
+__global__ void __launch_bounds__(256) pack_reference_kernel(const uint8_t* seq, uint64_t n, uint32_t* packed, uint16_t* nflags) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // thread = 16 bases
+    const uint64_t i0 = t * 16;
+    uint32_t w = 0, bad = 0;
+    if (i0 + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(seq + i0);
+        const uint32_t c[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            bad |= c[k] & 0xfcfcfcfcu;
+            const uint32_t x = c[k] & 0x03030303u;            // codes of 4 bases, one per byte -> 8 bits
+            const uint32_t y = (x | (x >> 6)) & 0x000f000fu;
+            w |= ((y | (y >> 12)) & 0xffu) << (8u * k);
+        }
+    } else {
+        bad = 1;
+        for (uint32_t k = 0; k < 16 && i0 + k < n; k++) w |= (uint32_t)(seq[i0 + k] & 3u) << (2u * k);
+    }
+    if (i0 < n) packed[t] = w;
+    const uint64_t b = __builtin_amdgcn_ballot_w64(bad != 0);
+    if ((threadIdx.x & 63u) == 0 && i0 < n) {
+        uint32_t f = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) f |= (((b >> (4u * j)) & 0xfULL) != 0 ? 1u : 0u) << j;
+        nflags[t >> 6] = (uint16_t)f;
     }
 }
 

@@ -21,13 +21,14 @@ struct jk_session {
     std::string out_prefix;
     // genome
     DevBuf d_seq, d_chrom_off, d_chrom_len, d_hdr_blob, d_hdr_off;
+    DevBuf d_packed, d_nflags;        // Illumina: 2-bit copy of d_seq + per-64-base "not only TCAG" flags (GenomeDev::packed)
     uint32_t n_chroms = 0;
     // tables
     IlluminaTables tables;
     DevBuf d_tab, d_mm2;
     bool lds_tables = false;
     size_t lds_bytes = 0, lds_launch = 0, evw_set = 0;
-    uint32_t lds_seg_off = 0;
+    uint32_t lds_seg_off = 0, lds_lut_off = 0;
     bool hap = false;
     bool hap_materialised = false;   // haplotype chromosomes written out in d_seq (no table lookups in the kernel)
     int compress = 0;          // 0 = plain FASTQ, 1..9 = compression level
