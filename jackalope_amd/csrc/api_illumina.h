@@ -350,6 +350,12 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     s.lds_seg_off = s.lds_tables ? (uint32_t)align_up(s.lds_bytes, 16) : 0;
     s.lds_lut_off = s.lds_seg_off;
     s.lds_launch = (s.lds_tables ? align_up(s.lds_bytes, 16) : 0) + seg_bytes + lut_bytes;
+    // the per-lane chromosome cache (32 bytes per lane), when there is room beside the tables and the 2.1 KB of static LDS
+    s.lds_cell_off = 0xffffffffu;
+    if (!seg_run && s.lds_launch + 32 * JK_ILL_BLOCK + 2304 <= 160 * 1024) {
+        s.lds_cell_off = (uint32_t)s.lds_launch;
+        s.lds_launch += 32 * JK_ILL_BLOCK;
+    }
     if (!seg_run) pack_reference(s);
 
     IlluminaKernelParams& P = s.kp;
@@ -368,6 +374,7 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
 
     P.lds_seg_off = s.lds_seg_off;
     P.lds_lut_off = s.lds_lut_off;
+    P.lds_cell_off = s.lds_cell_off;
     {
         const int lb = (int)s.lds_launch;
         auto allow = [&](const void* k) { JK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lb)); };

@@ -120,6 +120,7 @@ struct IlluminaKernelParams {
     uint32_t n_info, n_entries;
     uint32_t lds_seg_off;                                  // HAP: byte offset of the per-lane segment table in LDS
     uint32_t lds_lut_off;                                  // packed reference: byte offset of the 512-entry expansion table in LDS
+    uint32_t lds_cell_off;                                 // byte offset of the per-lane chromosome cache (8 x BLOCK words: tag, offset, id-line prefix), 0xffffffff: none
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -369,6 +370,7 @@ illumina_kernel(IlluminaKernelParams P) {
     }
     // packed reference: 8 bits (4 bases, ascending source order) -> the 4 code bytes in read order; entries 256..511 for
     // the reverse strand (descending source order, complemented: code ^ 2)
+    if (!SEG && P.lds_cell_off != 0xffffffffu) reinterpret_cast<uint32_t*>(smem + P.lds_cell_off)[threadIdx.x] = 0;     // chromosome cache: empty
     uint32_t* const s_lut = reinterpret_cast<uint32_t*>(smem + P.lds_lut_off);
     if (!SEG && P.g.packed) {
         for (uint32_t e = threadIdx.x; e < 512u; e += blockDim.x) {
@@ -423,15 +425,17 @@ illumina_kernel(IlluminaKernelParams P) {
 
     const uint32_t L = P.read_len;
     uint32_t bc = P.bc_len;                      // HAP: per haplotype, reloaded when the cursor moves
-    const uint64_t quota = P.lane_reads[lane];
-    uint64_t made = 0, in_pool = 0;
+    // (a lane's read count fits 32 bits: plan_lanes refuses more; 32-bit counters keep four more registers free)
+    const uint32_t quota = (uint32_t)P.lane_reads[lane];
+    uint32_t made = 0, in_pool = 0;
+    const uint32_t pool_size = P.pool_size > 0xffffffffULL ? 0xffffffffu : (uint32_t)P.pool_size;
 
     // chromosome cursor: the reference rescans from chromosome 0 for the first non-zero quota
     // (src/hts_illumina.cpp:199-200); quotas only ever decrease, so a monotone cursor is the same.
     // HAP: `ci` is the cell index hap * n_chroms + chrom, `n_cells` the number of cells.
     const uint32_t n_cells = HAP ? P.h.n_haps * P.g.n_chroms : P.g.n_chroms;
     uint32_t ci = 0;
-    uint64_t ccnt = n_cells ? P.chrom_reads[lane] : 0;
+    uint32_t ccnt = n_cells ? P.chrom_reads[lane] : 0;
     uint32_t cur_hap = 0xffffffffu;
 
     // the tile is the wave's: its offset and capacity are wave-uniform (scalar registers), a lane only adds its column
@@ -480,9 +484,27 @@ illumina_kernel(IlluminaKernelParams P) {
             if (frag_len >= chrom_len) { frag_len = chrom_len; frag_start = 0; }
             else frag_start = jk_frag_start(rng(), chrom_len - frag_len + 1);
         }
+        // Per-chromosome data of the read ends below -- the chromosome's offset in the sequence buffer and the id line's
+        // prefix -- come from eight LDS words per lane, refilled when the lane's cursor has moved to another chromosome
+        // (s_cell; word 0 = cell index + 1).  The waves of a SIMD are kept in step (wave balancing above), so the two
+        // dependent global loads the id line otherwise starts with stall all of them together: 4.7 % of the launch
+        // (tools/ablate notes in DESIGN.md section 4).  Without room in LDS (lds_cell_off = 0xffffffff) every read end
+        // loads them as before.
+        uint32_t* const s_cell = (!SEG && P.lds_cell_off != 0xffffffffu) ? reinterpret_cast<uint32_t*>(smem + P.lds_cell_off) + threadIdx.x : nullptr;
+        if (s_cell && s_cell[0] != ci + 1u) {
+            const uint64_t co = P.g.chrom_off[ci];
+            const uint32_t h0 = P.g.hdr_off[ci], hl = P.g.hdr_off[ci + 1] - h0;
+            const uint8_t* hp = P.g.hdr_blob + h0;            // (the blob is padded: the four loads need no bounds)
+            uint32_t w4[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) __builtin_memcpy(&w4[k], hp + 4u * k, 4);
+            s_cell[0] = ci + 1u; s_cell[BLOCK] = (uint32_t)co; s_cell[2 * BLOCK] = (uint32_t)(co >> 32); s_cell[3 * BLOCK] = hl;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) s_cell[(4 + k) * BLOCK] = w4[k];
+        }
         // ---- sample_indels + adjust_chrom_spaces (hts_illumina.cpp:117-184): one draw per fragment
         // position; anything but a match is rare and is recorded in the HBM bitmaps
-        uint32_t space[2], out_len[2], evalid[2];
+        uint32_t space_len[2], evalid[2];       // space | out_len << 16 (both are at most 2 * read_len < 2^16)
         const uint32_t fl32 = frag_len > 0xffffffffULL ? 0xffffffffu : (uint32_t)frag_len;
 #pragma unroll
         for (uint32_t r = 0; r < NE; r++) {
@@ -531,8 +553,7 @@ illumina_kernel(IlluminaKernelParams P) {
             }
             uint64_t sp = (uint64_t)L + n_del - n_ins;
             if (sp > frag_len) sp = frag_len;
-            space[r] = (uint32_t)sp;
-            out_len[r] = (uint32_t)sp - n_del + n_ins;
+            space_len[r] = (uint32_t)sp | (((uint32_t)sp - n_del + n_ins) << 16);
             evalid[r] = ev;
         }
         if (err) break;
@@ -541,7 +562,7 @@ illumina_kernel(IlluminaKernelParams P) {
         bool reverse = jk_runif_lt_half(rng());
 #pragma unroll
         for (uint32_t i = 0; i < NE; i++) {
-            const uint32_t sp = space[i], n_out = out_len[i];
+            const uint32_t sp = space_len[i] & 0xffffu, n_out = space_len[i] >> 16;
             uint32_t ev = evalid[i];
             const uint32_t ev_any = (ev | (ev >> 16)) & 0xffffu;      // words with any event
             const uint64_t cspace = (uint64_t)sp - bc;
@@ -572,17 +593,38 @@ illumina_kernel(IlluminaKernelParams P) {
                 }
             }
 
+            // (the pointer as a scalar pair of its own: left as a member of the kernel-argument block, every chunk load
+            // restores the block's whole 8-register tuple from its spill lanes -- v_readlane is a VALU instruction)
+            gbytes_t gseq = (gbytes_t)P.g.seq;
+            asm volatile("" : "+s"(gseq));
+            uint32_t pf[2] = {0, 0};
+            bool have_pf = false;
+            uint64_t coff = 0;
+            if (!SEG) coff = s_cell ? (((uint64_t)s_cell[2 * BLOCK] << 32) | s_cell[BLOCK]) : P.g.chrom_off[ci];
+
             // ---- FASTQ id line (fill_fq_lines, hts_illumina.cpp:286-312)
             OutStream& o = os[i];
             uint8_t* const col = P.pool[i] + tile_off + colb;
             {
                 // "@<genome>-<chrom>-": 4 bytes per load and append (the blob is padded, so the first four loads need no
                 // bounds; their latencies overlap)
-                const uint32_t h0 = P.g.hdr_off[ci], hlen = P.g.hdr_off[ci + 1] - h0;
-                const uint8_t* hp = P.g.hdr_blob + h0;
+                uint32_t h0 = 0, hlen;
                 uint32_t hw[4];
+                if (s_cell) {
+                    hlen = s_cell[3 * BLOCK];
 #pragma unroll
-                for (uint32_t k = 0; k < 4; k++) __builtin_memcpy(&hw[k], hp + 4u * k, 4);
+                    for (uint32_t k = 0; k < 4; k++) hw[k] = s_cell[(4 + k) * BLOCK];
+                    if (__builtin_amdgcn_ballot_w64(hlen > 16u) != 0) h0 = P.g.hdr_off[ci];
+                } else {
+                    h0 = P.g.hdr_off[ci]; hlen = P.g.hdr_off[ci + 1] - h0;
+                    const uint8_t* hp0 = P.g.hdr_blob + h0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) __builtin_memcpy(&hw[k], hp0 + 4u * k, 4);
+                    // (waited for here, on this path only: left pending, the compiler guards every later reuse of these
+                    // registers with a vmcnt wait on the common path too -- and vmcnt counts the pool stores as well)
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
+                }
+                const uint8_t* hp = P.g.hdr_blob + h0;
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
                     if (4u * k < hlen) {
@@ -655,10 +697,6 @@ illumina_kernel(IlluminaKernelParams P) {
             //    with compile-time shifts;
             //  * single bases, the general path (barcodes, indels, 'N', segment changes, uneven read lengths), until
             //    the output position is a multiple of 4 again and no lane needs it.
-            // (the pointer as a scalar pair of its own: left as a member of the kernel-argument block, every chunk load
-            // restores the block's whole 8-register tuple from its spill lanes -- v_readlane is a VALU instruction)
-            gbytes_t gseq = (gbytes_t)P.g.seq;
-            asm volatile("" : "+s"(gseq));
             const uint8_t* const bcode = HAP ? P.h.bc_blob + (size_t)cur_hap * JK_MAX_BARCODE : P.barcode;
             uint64_t A = 0;
             // HAP: the read is served segment by segment (reference runs and mutation bytes);
@@ -709,7 +747,7 @@ illumina_kernel(IlluminaKernelParams P) {
                     seg_end_pp = n > 1u ? s_seg[3 * BLOCK] : (q < sp ? q : 0xffffffffu);
                 }
             } else {
-                A = P.g.chrom_off[ci] + (reverse ? start + sp - 1 : start - bc);
+                A = coff + (reverse ? start + sp - 1 : start - bc);
             }
             // packed reference: may this read end take its 8-base blocks from the 2-bit copy?  (Its source window
             // [lo, lo + cspace) must not touch a flagged 64-base block, and the copy's byte offsets are kept in 32 bits.)
@@ -718,7 +756,7 @@ illumina_kernel(IlluminaKernelParams P) {
             gbytes_t pk = (gbytes_t)P.g.packed;
             asm volatile("" : "+s"(pk));
             if (!SEG && P.g.packed != nullptr && sp > bc) {
-                const uint64_t lo = P.g.chrom_off[ci] + start, last = lo + cspace - 1;
+                const uint64_t lo = coff + start, last = lo + cspace - 1;
                 const uint64_t b0 = lo >> 6;
                 const uint32_t nb = (uint32_t)((last >> 6) - b0) + 1u;
                 uint32_t fw;
@@ -800,8 +838,7 @@ illumina_kernel(IlluminaKernelParams P) {
             // the 8-base gear loads one block ahead: the chunk of the NEXT 8 positions is requested when this block starts,
             // so its latency (and that of the pool stores queued before it) has a whole block to pass; it is used only if
             // the next iteration takes the 8-base gear again (then every lane has advanced by exactly 8)
-            uint32_t pf[2] = {0, 0};
-            bool have_pf = false;
+
             while (op < n_out) {
                 // ---- gear choice (wave-uniform)
                 uint32_t nquads = 0, room = 0;
@@ -995,11 +1032,11 @@ illumina_kernel(IlluminaKernelParams P) {
         const bool dup = P.dup_all || xd < P.th_dup;
         // the duplicate loop only continues while the pool has room and the quota is not met; a
         // full pool (or met quota) is flushed, which on the GPU only resets the counter
-        if (dup && made < quota && in_pool < P.pool_size) {
+        if (dup && made < quota && in_pool < pool_size) {
             is_dup = true;
         } else {
             is_dup = false;
-            if (in_pool >= P.pool_size || made >= quota) in_pool = 0;
+            if (in_pool >= pool_size || made >= quota) in_pool = 0;
         }
     }
 

@@ -28,7 +28,7 @@ struct jk_session {
     DevBuf d_tab, d_mm2;
     bool lds_tables = false;
     size_t lds_bytes = 0, lds_launch = 0, evw_set = 0;
-    uint32_t lds_seg_off = 0, lds_lut_off = 0;
+    uint32_t lds_seg_off = 0, lds_lut_off = 0, lds_cell_off = 0xffffffffu;
     bool hap = false;
     bool hap_materialised = false;   // haplotype chromosomes written out in d_seq (no table lookups in the kernel)
     int compress = 0;          // 0 = plain FASTQ, 1..9 = compression level
