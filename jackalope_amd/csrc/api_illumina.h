@@ -69,7 +69,7 @@ static void setup_model(jk_session& s, const jk_illumina_args& a) {
     s.tables = build_illumina_tables(a);
     const uint32_t L = s.tables.read_length;
     s.ev_words = (2 * L + 63) / 64 + 1;
-    if (s.ev_words > (uint32_t)JK_MAX_EVW) throw Error(JK_ERR_UNSUPPORTED, "read lengths above 480 are not implemented on the GPU path");
+    if (s.ev_words > (uint32_t)JK_MAX_EVW_LONG) throw Error(JK_ERR_UNSUPPORTED, "read lengths above 992 are not implemented on the GPU path");
 
     IlluminaKernelParams& P = s.kp;
     P.read_len = L; P.n_ends = s.n_ends; P.paired = s.paired; P.matepair = (s.paired && a.matepair) ? 1 : 0;
@@ -346,7 +346,8 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     const bool seg_run = s.hap && !s.hap_materialised;
     const size_t seg_bytes = seg_run ? (size_t)JK_HAP_SEGS * 12 * JK_ILL_BLOCK : 0;
     const size_t lut_bytes = seg_run ? 0 : 2048;
-    s.lds_tables = s.lds_bytes + seg_bytes + lut_bytes <= 156 * 1024;
+    // (reads above 480 need the 64-bit event masks, which only the kernels with the tables in global memory have)
+    s.lds_tables = s.lds_bytes + seg_bytes + lut_bytes <= 156 * 1024 && s.ev_words <= (uint32_t)JK_MAX_EVW;
     s.lds_seg_off = s.lds_tables ? (uint32_t)align_up(s.lds_bytes, 16) : 0;
     s.lds_lut_off = s.lds_seg_off;
     s.lds_launch = (s.lds_tables ? align_up(s.lds_bytes, 16) : 0) + seg_bytes + lut_bytes;

@@ -25,12 +25,14 @@
 // HiSeq 2500 / 150 bp pair of profiles -> one 1024-thread workgroup per CU, 4 waves per SIMD);
 // profiles that do not fit in LDS are read through L2 instead (template parameter).
 #pragma once
+#include <type_traits>
 #include "jk_math.h"
 
 namespace jk {
 
-constexpr int JK_MAX_BARCODE = 480;      // a barcode is shorter than the read, and reads are at most 480 long (JK_MAX_EVW)
-constexpr int JK_MAX_EVW = 16;         // 64-bit words of indel-event bitmaps per read end (positions < 1024)
+constexpr int JK_MAX_BARCODE = 992;      // a barcode is shorter than the read, and reads are at most 992 long (JK_MAX_EVW_LONG)
+constexpr int JK_MAX_EVW = 16;         // 64-bit words of indel-event bitmaps per read end (positions < 1024) -- kernels with the tables in LDS
+constexpr int JK_MAX_EVW_LONG = 32;    // -- kernels with the tables in global memory (64-bit word masks): read lengths up to 992
 constexpr uint32_t JK_HAP_BUCKET_SHIFT = 10;   // 1024 haplotype positions per bucket of the mutation index
 constexpr uint32_t JK_HAP_SEGS = 3;    // segments of a read window kept in the per-lane LDS table (haplotype runs)
 
@@ -504,11 +506,16 @@ illumina_kernel(IlluminaKernelParams P) {
         }
         // ---- sample_indels + adjust_chrom_spaces (hts_illumina.cpp:117-184): one draw per fragment
         // position; anything but a match is rare and is recorded in the HBM bitmaps
-        uint32_t space_len[2], evalid[2];       // space | out_len << 16 (both are at most 2 * read_len < 2^16)
+        // which bitmap words a read end has written: insertion words in the low half, deletion words in the high half of a
+        // 32-bit mask (16 words, reads up to 480) when the tables sit in LDS, of a 64-bit mask (32 words, up to 992) otherwise
+        using ev_t = typename std::conditional<LDS_TAB, uint32_t, uint64_t>::type;
+        constexpr uint32_t DSH = LDS_TAB ? 16u : 32u;
+        constexpr ev_t HALF = LDS_TAB ? (ev_t)0xffffu : (ev_t)0xffffffffu;
+        uint32_t space_len[2]; ev_t evalid[2];       // space | out_len << 16 (both are at most 2 * read_len + 64 < 2^16)
         const uint32_t fl32 = frag_len > 0xffffffffULL ? 0xffffffffu : (uint32_t)frag_len;
 #pragma unroll
         for (uint32_t r = 0; r < NE; r++) {
-            uint32_t frag_pos = 0, len_now = 0, n_ins = 0, n_del = 0, ev = 0;
+            uint32_t frag_pos = 0, len_now = 0, n_ins = 0, n_del = 0; ev_t ev = 0;
             const uint64_t thm = P.th_match[r], thd = P.th_del[r];
             const bool nm = P.never_match[r], nd = P.never_del[r];
             auto indel_event = [&](uint64_t x) {     // the draw at frag_pos was not a match
@@ -516,11 +523,11 @@ illumina_kernel(IlluminaKernelParams P) {
                 if (!is_del && len_now == L - 1) { len_now++; return; }       // insertion after the last base: counted, not recorded
                 const uint32_t w = frag_pos >> 6;
                 if (w >= W) { err |= JK_KERR_TOO_MANY_DELETIONS; len_now = L; return; }
-                const uint32_t vb = (is_del ? 16u : 0u) + w;
+                const uint32_t vb = (is_del ? DSH : 0u) + w;
                 uint64_t* a = evaddr(r, is_del ? 1u : 0u, w);
                 const uint64_t old = ((ev >> vb) & 1u) ? *a : 0ULL;
                 *a = old | (1ULL << (frag_pos & 63u));
-                ev |= 1u << vb;
+                ev |= (ev_t)1 << vb;
                 if (is_del) n_del++; else { n_ins++; len_now += 2; }
             };
             // Matches are all but ~3e-4 of the draws, and until an event the lanes of a wave are at the same
@@ -563,15 +570,15 @@ illumina_kernel(IlluminaKernelParams P) {
 #pragma unroll
         for (uint32_t i = 0; i < NE; i++) {
             const uint32_t sp = space_len[i] & 0xffffu, n_out = space_len[i] >> 16;
-            uint32_t ev = evalid[i];
-            const uint32_t ev_any = (ev | (ev >> 16)) & 0xffffu;      // words with any event
+            ev_t ev = evalid[i];
+            const uint32_t ev_any = (uint32_t)((ev | (ev >> DSH)) & HALF);      // words with any event
             const uint64_t cspace = (uint64_t)sp - bc;
             uint64_t start;
             if ((!P.matepair && !reverse) || (P.matepair && reverse)) start = frag_start;
             else start = frag_start + frag_len - cspace;
 
             // inserted bases are drawn first, right to left (hts_illumina.h:213-225)
-            if (ev & 0xffffu) {
+            if (ev & HALF) {
                 for (int w = (int)W - 1; w >= 0; w--) {
                     if (!((ev >> w) & 1u)) continue;
                     uint64_t rest = *evaddr(i, 0, w), b0 = 0, b1 = 0, nul = 0;
@@ -587,8 +594,8 @@ illumina_kernel(IlluminaKernelParams P) {
                     *evaddr(i, 2, w) = b0; *evaddr(i, 3, w) = b1;
                     if (nul) {
                         uint64_t* a = evaddr(i, 1, w);
-                        *a = (((ev >> (16 + w)) & 1u) ? *a : 0ULL) | nul;
-                        ev |= 1u << (16 + w);
+                        *a = (((ev >> (DSH + w)) & 1u) ? *a : 0ULL) | nul;
+                        ev |= (ev_t)1 << (DSH + w);
                     }
                 }
             }
@@ -774,7 +781,7 @@ illumina_kernel(IlluminaKernelParams P) {
             auto next_event = [&](uint32_t pp) -> uint32_t {
                 for (uint32_t w = pp >> 6; w < W; w++) {
                     if (!((ev_any >> w) & 1u)) continue;
-                    uint64_t m = (((ev >> w) & 1u) ? *evaddr(i, 0, w) : 0ULL) | (((ev >> (16 + w)) & 1u) ? *evaddr(i, 1, w) : 0ULL);
+                    uint64_t m = (((ev >> w) & 1u) ? *evaddr(i, 0, w) : 0ULL) | (((ev >> (DSH + w)) & 1u) ? *evaddr(i, 1, w) : 0ULL);
                     if (w == (pp >> 6)) m &= ~0ULL << (pp & 63u);
                     if (m) return w * 64u + (uint32_t)__builtin_ctzll(m);
                 }
@@ -980,7 +987,7 @@ illumina_kernel(IlluminaKernelParams P) {
                     } else {
                         for (;;) {
                             const uint32_t w = pp >> 6, bit = pp & 63u;
-                            const bool deleted = w < W && ((ev >> (16 + w)) & 1u) && ((*evaddr(i, 1, w) >> bit) & 1ULL) &&
+                            const bool deleted = w < W && ((ev >> (DSH + w)) & 1u) && ((*evaddr(i, 1, w) >> bit) & 1ULL) &&
                                                  !(((ev >> w) & 1u) && ((*evaddr(i, 0, w) >> bit) & 1ULL));     // (both bits: a NUL insertion)
                             if (!deleted) break;
                             pp++;
@@ -990,7 +997,7 @@ illumina_kernel(IlluminaKernelParams P) {
                         if (w < W && ((ev >> w) & 1u) && ((*evaddr(i, 0, w) >> bit) & 1ULL)) {
                             pending = true;
                             pend_base = (uint32_t)((*evaddr(i, 2, w) >> bit) & 1ULL) | ((uint32_t)((*evaddr(i, 3, w) >> bit) & 1ULL) << 1);
-                            if (((ev >> (16 + w)) & 1u) && ((*evaddr(i, 1, w) >> bit) & 1ULL)) pend_base = 4u;      // inserted NUL: not TCAG
+                            if (((ev >> (DSH + w)) & 1u) && ((*evaddr(i, 1, w) >> bit) & 1ULL)) pend_base = 4u;      // inserted NUL: not TCAG
                         }
                         pp++;
                     }

@@ -111,6 +111,40 @@ def test_other_builtin_profiles(ja, O, read_length):
     check(ja, O, g, read_length, 2400, 12, job(frag_mean=600.0, frag_sd=120.0))
 
 
+def write_random_profile(path, n_pos, seed):
+    """An ART-format profile (R/hts_illumina.R:211-262) with three to five qualities per position and base."""
+    rng = np.random.default_rng(seed)
+    with open(path, "w") as fh:
+        for nt in "ACGT":
+            for pos in range(n_pos):
+                k = int(rng.integers(3, 6))
+                quals = np.sort(rng.choice(np.arange(2, 42), size=k, replace=False))
+                cum = np.cumsum(rng.integers(1, 1000, size=k))
+                fh.write("%s\t%d\t%s\n" % (nt, pos, "\t".join(str(int(q)) for q in quals)))
+                fh.write("%s\t%d\t%s\n" % (nt, pos, "\t".join(str(int(c)) for c in cum)))
+    return path
+
+
+@pytest.mark.parametrize("read_length", [481, 600, 992])
+def test_reads_longer_than_480(ja, O, tmp_path, read_length):
+    """Custom profiles may be longer than any instrument's reads (R/hts_illumina.R:211-262 takes whatever the file holds).
+    Above 480 the run uses the kernels with 64-bit event-word masks (csrc/jk_illumina_kernel.h: ev_t); 992 is their limit."""
+    g = ja.synthetic_genome([400_000, 9_000], seed=14)
+    p1 = write_random_profile(str(tmp_path / "p1.txt"), read_length, 1)
+    p2 = write_random_profile(str(tmp_path / "p2.txt"), read_length, 2)
+    check(ja, O, g, read_length, 1200, 70, job(frag_mean=3.0 * read_length, frag_sd=0.5 * read_length), profiles=(p1, p2))
+    # indel-heavy: events in bitmap words beyond the 16th, fragments shorter than the read
+    check(ja, O, g, read_length, 800, 64, job(frag_mean=1.5 * read_length, frag_sd=0.8 * read_length, ins_prob1=0.01, del_prob1=0.02,
+                                             ins_prob2=0.02, del_prob2=0.01), profiles=(p1, p2), seed=5)
+    # a long barcode (more than 480 bases for the two longer reads)
+    check(ja, O, g, read_length, 400, 64, job(frag_mean=3.0 * read_length, frag_sd=0.5 * read_length,
+                                             barcode=("GATTACAT" * 124)[:min(read_length - 20, 700)]), profiles=(p1, p2))
+    if read_length == 992:
+        p3 = write_random_profile(str(tmp_path / "p3.txt"), 993, 3)
+        with pytest.raises(ja.JackalopeHipError, match="above 992"):
+            ja.illumina(g, None, 100, 993, False, profile1=p3, n_threads=4, seed_words=ja.seed_words(1, 64), _session=True)
+
+
 def test_gamma_shapes(ja, O):
     g = ja.synthetic_genome([300_000], seed=13)
     check(ja, O, g, 150, 4000, 20, job(frag_mean=300.0, frag_sd=300.0))     # shape 1
