@@ -184,11 +184,13 @@ pacbio_kernel(PacbioKernelParams P) {
     jk_gamma_state ln_st; ln_st.saved = 0.0; ln_st.saved_available = 0; ln_st.fail = 0;     // lognormal_distribution::_M_nd
     jk_gamma_state chi_st; chi_st.saved = 0.0; chi_st.saved_available = 0; chi_st.fail = 0;  // chi_squared -> gamma -> _M_nd
 
-    uint64_t quota = valid ? P.lane_reads[lane] : 0;
-    uint64_t made = 0, in_pool = 0;
+    // (a lane's read count fits 32 bits: plan_lanes refuses more)
+    uint32_t quota = valid ? (uint32_t)P.lane_reads[lane] : 0;
+    uint32_t made = 0, in_pool = 0;
+    const uint32_t pool_size = P.pool_size > 0xffffffffULL ? 0xffffffffu : (uint32_t)P.pool_size;
     const uint32_t n_cells = HAP ? P.h.n_haps * P.g.n_chroms : P.g.n_chroms;
     uint32_t ci = 0;
-    uint64_t ccnt = (n_cells && valid) ? P.chrom_reads[lane] : 0;
+    uint32_t ccnt = (n_cells && valid) ? P.chrom_reads[lane] : 0;
     uint32_t cur_hap = 0xffffffffu;
 
     // what follows from the lane's identity (set again whenever the thread takes over another lane)
@@ -301,10 +303,10 @@ pacbio_kernel(PacbioKernelParams P) {
                            ((uint32_t)ln_st.fail << 5) | ((uint32_t)chi_st.fail << 6));
             put(rng.e.s0); put(rng.e.s1); put(rng.e.s2); put(rng.e.s3); put64(rng.e.inc_lo); put64(rng.e.inc_hi);
             put64(jk_d2u(ln_st.saved)); put64(jk_d2u(chi_st.saved));
-            put64(quota); put64(made); put64(in_pool); put(ci); put64(ccnt); put(cur_hap);
+            put(quota); put(made); put(in_pool); put(ci); put(ccnt); put(cur_hap);
             put64((uint64_t)(uintptr_t)o.gp); put(o.off); put64(o.pos); put(err);
             put64(L); put64(read_start); put64(chrom_len); put(hdepth); put64(buf_size);
-            static_assert(PB_XCHG_WORDS >= 42, "lane state does not fit its exchange record");
+            static_assert(PB_XCHG_WORDS >= 38, "lane state does not fit its exchange record");
             __syncthreads();
             const uint32_t* gp = P.xchg + wg0 + my_slot;
             k = 0;
@@ -316,7 +318,7 @@ pacbio_kernel(PacbioKernelParams P) {
             ln_st.saved_available = (fl >> 3) & 1u; chi_st.saved_available = (fl >> 4) & 1u; ln_st.fail = (fl >> 5) & 1u; chi_st.fail = (fl >> 6) & 1u;
             rng.e.s0 = get(); rng.e.s1 = get(); rng.e.s2 = get(); rng.e.s3 = get(); rng.e.inc_lo = get64(); rng.e.inc_hi = get64();
             ln_st.saved = jk_u2d(get64()); chi_st.saved = jk_u2d(get64());
-            quota = get64(); made = get64(); in_pool = get64(); ci = get(); ccnt = get64(); cur_hap = get();
+            quota = get(); made = get(); in_pool = get(); ci = get(); ccnt = get(); cur_hap = get();
             o.gp = reinterpret_cast<uint8_t*>((uintptr_t)get64()); o.off = get(); o.pos = get64(); err = get();
             L = get64(); read_start = get64(); chrom_len = get64(); hdepth = get(); buf_size = get64();
             bind_lane();
@@ -771,8 +773,8 @@ pacbio_kernel(PacbioKernelParams P) {
         made += 1; in_pool += 1;
         const uint64_t xd = rng();
         const bool dup = P.dup_all || xd < P.th_dup;
-        if (dup && made < quota && in_pool < P.pool_size) is_dup = true;
-        else { is_dup = false; if (in_pool >= P.pool_size || made >= quota) in_pool = 0; }
+        if (dup && made < quota && in_pool < pool_size) is_dup = true;
+        else { is_dup = false; if (in_pool >= pool_size || made >= quota) in_pool = 0; }
         } while (0);
     }
     if (valid) {
