@@ -10,14 +10,14 @@ namespace jk {
 // bytes have left the device.
 struct StreamCtx {
     jk_session& s;
-    HostPipe pipe;
+    HostPipe& pipe;
     std::vector<std::unique_ptr<FastqFile>> files;
     std::mutex m; std::condition_variable cv;
     std::deque<int> q; bool closed = false;
     int consumed = -1;                   // last batch whose image has left the device
     int err_code = 0; std::string err;
     std::thread th;
-    StreamCtx(jk_session& s_, const std::string& suffix) : s(s_), pipe(PIPE_PIECE, 6, pipe_writers()) {
+    StreamCtx(jk_session& s_, const std::string& suffix) : s(s_), pipe(session_pipe(s_)) {
         for (uint32_t e = 0; e < s.n_ends; e++) files.emplace_back(new FastqFile(s, e, suffix));
         th = std::thread([this] { run(); });
     }

@@ -342,12 +342,20 @@ inline int pipe_writers() {
     return 4;
 }
 
+// The session's host pipe: 200 MB of pinned memory and the writer threads, allocated once per session (hipHostMalloc of
+// the ring takes tens of milliseconds -- as long as the D2H copy of a small job's whole output).
+static HostPipe& session_pipe(const jk_session& s) {
+    jk_session& m = const_cast<jk_session&>(s);
+    if (!m.host_pipe) m.host_pipe = std::make_shared<HostPipe>(PIPE_PIECE, 6, pipe_writers());
+    return *m.host_pipe;
+}
+
 // A lane shard's image at its place in the shared file (see jk_session_write_shard).
 static void write_shard(const jk_session& s, const uint64_t* file_offset) {
     if (!s.generated) throw Error(JK_ERR_ARG, "jk_session_write_shard before jk_session_generate");
     if (s.compress > 0) throw Error(JK_ERR_UNSUPPORTED, "lane shards write uncompressed FASTQ only (compress the assembled file, or give each rank its own out_prefix)");
     if (s.out_prefix.empty()) throw Error(JK_ERR_ARG, "out_prefix is empty");
-    HostPipe pipe(PIPE_PIECE, 6, pipe_writers());
+    HostPipe& pipe = session_pipe(s);
     for (uint32_t e = 0; e < s.n_ends; e++) {
         FastqFile f(s, e, "", false, file_offset[e]);
         f.add(pipe, s.d_out[e].as<uint8_t>(), s.bytes[e]);
@@ -363,7 +371,7 @@ static void write_files(const jk_session& s) {
         throw Error(JK_ERR_UNSUPPORTED, "this session holds lanes " + std::to_string(s.lane_begin) + ".." + std::to_string(s.lane_end) + " of " +
                     std::to_string(s.n_lanes_total) + ": writing it as the whole file would drop the other lanes' reads -- use "
                     "jk_session_write_shard with the byte offsets from the ranks' jk_session_sizes");
-    HostPipe pipe(PIPE_PIECE, 6, pipe_writers());
+    HostPipe& pipe = session_pipe(s);
     for (uint32_t e = 0; e < s.n_ends; e++) {
         FastqFile f(s, e);
         f.add(pipe, s.d_out[e].as<uint8_t>(), s.bytes[e]);

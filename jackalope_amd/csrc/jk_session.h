@@ -1,6 +1,7 @@
 // jk_session.h -- state of one sequencing run (what jk_*_open returns)
 // (part of the one translation unit jk_api.hip; see the include list there)
 #pragma once
+#include <memory>
 #include <atomic>
 
 
@@ -9,6 +10,8 @@
 #endif
 
 using namespace jk;
+
+namespace jk { class HostPipe; }
 
 struct jk_session {
     int device = 0;
@@ -21,6 +24,7 @@ struct jk_session {
     std::string out_prefix;
     // genome
     DevBuf d_seq, d_chrom_off, d_chrom_len, d_hdr_blob, d_hdr_off;
+    std::shared_ptr<jk::HostPipe> host_pipe;     // pinned ring + writer threads of the sinks, made on first use and kept (api_sinks.h)
     DevBuf d_packed, d_nflags;        // Illumina: 2-bit copy of d_seq + per-64-base "not only TCAG" flags (GenomeDev::packed)
     uint32_t n_chroms = 0;
     // tables
