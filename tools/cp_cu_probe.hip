@@ -10,6 +10,7 @@ using namespace jk;
 __global__ void __launch_bounds__(1024) blocker_kernel(uint64_t ticks) {
     extern __shared__ uint32_t blk_lds[];
     if (threadIdx.x == 0) blk_lds[0] = 1;
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");      // 128 VGPRs x 16 waves: the whole register file, like the generator -- nothing else fits on the CU
     const uint64_t t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
