@@ -62,7 +62,7 @@ static void setup_model(jk_session& s, const jk_illumina_args& a) {
     if (a.stream_output) s.streaming = true;
     JK_HIP(hipSetDevice(s.device));
     create_generator_stream(s);
-    JK_HIP(hipStreamCreateWithFlags(&s.cp_stream, hipStreamNonBlocking));
+    create_compaction_stream(s);
     JK_HIP(hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking));
     if (const char* e = std::getenv("JK_TWO_GEN_STREAMS")) s.two_gen_streams = std::atoi(e) != 0;
 

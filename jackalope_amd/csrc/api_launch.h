@@ -120,6 +120,7 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
             uint64_t* lo = s.d_lane_off[0].as<uint64_t>() + B.lane0;
             uint64_t* bs = s.d_block_sums.as<uint64_t>();
             uint64_t* base = s.d_base[0].as<uint64_t>() + b;
+            if (b + 1 < s.batches.size()) hipLaunchKernelGGL(pb_delay_kernel, dim3(1), dim3(64), 0, s.cp_stream, (uint64_t)100000);   // 1 ms
             hipLaunchKernelGGL(scan_block_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lb, lo, bs, B.n_lanes);
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.cp_stream, bs, nbp, base);
             hipLaunchKernelGGL(scan_add_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lo, bs, B.n_lanes);

@@ -26,7 +26,7 @@ static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a
     if (a.stream_output) s.streaming = true;
     JK_HIP(hipSetDevice(s.device));
     create_generator_stream(s);
-    JK_HIP(hipStreamCreateWithFlags(&s.cp_stream, hipStreamNonBlocking));
+    create_compaction_stream(s);
 
     PacbioHostModel M;
     PacbioKernelParams& P = s.kpb;

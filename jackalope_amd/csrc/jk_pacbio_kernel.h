@@ -786,4 +786,15 @@ pacbio_kernel(PacbioKernelParams P) {
     if (err) atomicOr(P.err, err);
 }
 
+// One wave that waits on the clock.  It heads the compaction chain of a PacBio launch: the generator has exactly as many
+// workgroups as the device has slots for them, and the next launch and this chain become ready at the same moment -- a
+// compaction workgroup that takes a slot first keeps a generator workgroup waiting until the first ones retire, 21 ms
+// into a 29 ms launch (launches of 40 ms instead of 32, one or two per step at random; with RCCL in the process most
+// steps: 21.7 instead of 24.2 M reads/s).  A millisecond later the generator's workgroups are all placed; the chain has
+// twenty to spare.  `ticks` in units of wall_clock64 (100 MHz).
+__global__ void __launch_bounds__(64) pb_delay_kernel(uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 }  // namespace jk

@@ -96,4 +96,11 @@ static void create_generator_stream(jk_session& s) {
     JK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     JK_HIP(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, greatest));
 }
+// The scan + compaction stream at the lowest priority: when a generator launch and the previous launch's compaction
+// become ready together, the generator's workgroups should be placed first (see also pb_delay_kernel).
+static void create_compaction_stream(jk_session& s) {
+    int least = 0, greatest = 0;
+    JK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    JK_HIP(hipStreamCreateWithPriority(&s.cp_stream, hipStreamNonBlocking, least));
+}
 }  // namespace jk

@@ -1,5 +1,6 @@
 """PacBio configs[4] on one GPU with a chosen launch size and pool cap: does a launch of two workgroups per slot (the
-second dealt dynamically as the first retire) beat two launches?    python tools/pacbio_launch_probe.py <batch lanes> <cap GB>"""
+second dealt dynamically as the first retire) beat two launches?  Do more reads per lane (fewer lanes) shorten the
+under-occupied end of a launch?    python tools/pacbio_launch_probe.py <batch lanes> <cap GB> [lanes = 2^21]"""
 import os
 import sys
 import time
@@ -9,7 +10,7 @@ batch, cap = int(sys.argv[1]), float(sys.argv[2])
 os.environ["JK_BATCH_LANES"] = str(batch)
 import jackalope_amd as ja  # noqa: E402
 
-lanes = 1 << 21
+lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 21
 genome = ja.synthetic_genome([3_000_000_000], seed=3)
 lens = list(range(5000, 15001, 500))
 words = ja.seed_words(12345, 16 * lanes)
@@ -20,4 +21,4 @@ with s:
         t = time.time(); s.generate(); dt = time.time() - t
         best = dt if best is None or dt < best else best
     sizes, reads = s.sizes()
-    print("batch lanes %d, cap %.0f GB: %d launches, %.1f ms -> %.2f M reads/s" % (batch, cap, s.n_batches(), best * 1e3, reads / best / 1e6), flush=True)
+    print("lanes %d, batch lanes %d, cap %.0f GB: %d launches, %.1f ms -> %.2f M reads/s" % (lanes, batch, cap, s.n_batches(), best * 1e3, reads / best / 1e6), flush=True)
