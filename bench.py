@@ -25,8 +25,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Lanes per GPU: a generator launch takes 224 workgroups of 1024 lanes (the other 32 CUs run the compaction of the
-# launch before); four launches per step, 10.9 pairs per lane on the headline workload.
-DEFAULT_LANES = 4 * 224 * 1024
+# launch before), the first launch of a step all 256; four launches per step, 10.5 pairs per lane on
+# the headline workload.
+DEFAULT_LANES = (256 + 3 * 224) * 1024
 
 
 def cpu_baseline(genome, prof1, prof2, read_length, sample_pairs, cores):
@@ -450,7 +451,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--lanes", type=int, default=DEFAULT_LANES, help="generator lanes per GPU (default: four launches of 224 x 1024)")
+    ap.add_argument("--lanes", type=int, default=DEFAULT_LANES, help="generator lanes per GPU (default: four launches, the first of 256 x 1024 lanes, three of 224 x 1024)")
     ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU (30x of 100 Mbp at PE150)")
     ap.add_argument("--genome-mbp", type=float, default=100.0)
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = choose for about 15 s of CPU work")

@@ -166,7 +166,7 @@ static void upload_quotas(jk_session& s, const LanePlan& lp, const QuotaModel& Q
 // refuses to write past it (JK_KERR_IMAGE_FULL).
 static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint64_t lanes_per_batch,
                                   const std::vector<uint64_t>& lane_cap, const LanePlan& lp, const QuotaModel& Q,
-                                  uint64_t image_hint = 0) {
+                                  uint64_t image_hint = 0, uint64_t first_batch_lanes = 0) {
     const std::vector<uint64_t>& lane_reads = lp.lane_reads;
     const std::vector<uint32_t>& lane_seeds = lp.lane_seeds;
     PhaseTimer pt("pools: plan, alloc, upload");
@@ -184,7 +184,8 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
             s.batch_pool_off_index.push_back(pool_off.size());
             pool_off.push_back(0);
             uint64_t used = 0;
-            while (l < s.n_shard && b.n_lanes < max_batch_lanes) {
+            const uint64_t lane_limit = (l == 0 && first_batch_lanes) ? first_batch_lanes : max_batch_lanes;
+            while (l < s.n_shard && b.n_lanes < lane_limit) {
                 const uint64_t tl = std::min<uint64_t>(64, s.n_shard - l);
                 uint64_t mx = 0;
                 for (uint64_t k = 0; k < tl; k++) mx = std::max(mx, lane_cap[l + k]);
@@ -333,7 +334,15 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     if (const char* e = std::getenv("JK_COMPACT_CUS")) { const long v = std::atol(e); if (v >= 0 && v < n_cu) reserve = (uint64_t)v; }
     uint64_t launch_lanes = (uint64_t)n_cu * JK_ILL_BLOCK;
     if (s.n_shard > launch_lanes) launch_lanes = ((uint64_t)n_cu - reserve) * JK_ILL_BLOCK;
-    const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, launch_lanes, lane_cap, lp, Q);
+    // The first launch of a run of several has no compaction beside it: it takes every CU (and the third pool set below
+    // absorbs its larger compaction).  JK_FIRST_LAUNCH_FULL=0: all launches alike.
+    uint64_t first_lanes = 0;
+    if (s.n_shard > launch_lanes && launch_lanes < (uint64_t)n_cu * JK_ILL_BLOCK) {
+        first_lanes = (uint64_t)n_cu * JK_ILL_BLOCK;
+        if (const char* e = std::getenv("JK_FIRST_LAUNCH_FULL")) if (std::atoi(e) == 0) first_lanes = 0;
+        if (std::getenv("JK_BATCH_LANES")) first_lanes = 0;
+    }
+    const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, launch_lanes, lane_cap, lp, Q, 0, first_lanes);
     const IlluminaPacked packed = pack_illumina_tables(s.tables);
     s.d_tab.upload(packed.tab);
     s.d_mm2.upload(packed.mm2);
