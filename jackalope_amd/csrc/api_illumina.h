@@ -357,9 +357,15 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     const size_t lut_bytes = seg_run ? 0 : 2048;
     // (reads above 480 need the 64-bit event masks, which only the kernels with the tables in global memory have)
     s.lds_tables = s.lds_bytes + seg_bytes + lut_bytes <= 156 * 1024 && s.ev_words <= (uint32_t)JK_MAX_EVW;
-    s.lds_seg_off = s.lds_tables ? (uint32_t)align_up(s.lds_bytes, 16) : 0;
+    // tables in global memory: their {entry offset, entry count} part (8 bytes per end, position and nucleotide) goes to
+    // LDS all the same when it fits beside the rest
+    const size_t info_bytes = (size_t)s.tables.info.size() * 8;
+    const bool info_lds = !s.lds_tables && info_bytes + seg_bytes + lut_bytes + 2304 <= 120 * 1024;
+    const size_t front = s.lds_tables ? align_up(s.lds_bytes, 16) : (info_lds ? align_up(info_bytes, 16) : 0);
+    s.lds_seg_off = (uint32_t)front;
     s.lds_lut_off = s.lds_seg_off;
-    s.lds_launch = (s.lds_tables ? align_up(s.lds_bytes, 16) : 0) + seg_bytes + lut_bytes;
+    s.lds_launch = front + seg_bytes + lut_bytes;
+    s.kp.info_in_lds = info_lds ? 1u : 0u;
     // the per-lane chromosome cache (32 bytes per lane), when there is room beside the tables and the 2.1 KB of static LDS
     s.lds_cell_off = 0xffffffffu;
     if (!seg_run && s.lds_launch + 32 * JK_ILL_BLOCK + 2304 <= 160 * 1024) {

@@ -122,6 +122,7 @@ struct IlluminaKernelParams {
     uint32_t n_info, n_entries;
     uint32_t lds_seg_off;                                  // HAP: byte offset of the per-lane segment table in LDS
     uint32_t lds_lut_off;                                  // packed reference: byte offset of the 512-entry expansion table in LDS
+    uint32_t info_in_lds;                                  // tables in global memory: their {offset, count} part is staged at the start of LDS
     uint32_t lds_cell_off;                                 // byte offset of the per-lane chromosome cache (8 x BLOCK words: tag, offset, id-line prefix), 0xffffffff: none
 };
 
@@ -368,8 +369,16 @@ illumina_kernel(IlluminaKernelParams P) {
             s_tab[i] = P.tab[i] + ((i < 2u * P.n_info && !(i & 1u)) ? lds_base : 0u);
         T.tab = smem;
     } else {
+        // profiles whose alias entries do not fit in LDS (every built-in one but HiSeq 2500 150 bp) still have a small
+        // {entry offset, entry count} table -- 8 bytes per (end, position, nucleotide): 16 KB at 250 bases -- which is
+        // staged when there is room (info_in_lds): one dependent global load per base instead of two
+        if (P.info_in_lds) {
+            uint32_t* s_tab = reinterpret_cast<uint32_t*>(smem);
+            for (uint32_t i = threadIdx.x; i < 2u * P.n_info; i += blockDim.x) s_tab[i] = P.tab[i];
+        }
         T.tab = reinterpret_cast<const uint8_t*>(P.tab);
     }
+    const bool info_lds = LDS_TAB || P.info_in_lds;
     // packed reference: 8 bits (4 bases, ascending source order) -> the 4 code bytes in read order; entries 256..511 for
     // the reverse strand (descending source order, complemented: code ^ 2)
     if (!SEG && P.lds_cell_off != 0xffffffffu) reinterpret_cast<uint32_t*>(smem + P.lds_cell_off)[threadIdx.x] = 0;     // chromosome cache: empty
@@ -815,7 +824,8 @@ illumina_kernel(IlluminaKernelParams P) {
             // base with code c (c8 = 8*c) at output position `opos`: returns 8 * quality character, sets `mism`
             // (x1 = the step's first draw: made by the caller, because a non-TCAG position uses it differently)
             auto qual_step = [&](uint32_t c8, uint32_t opos, uint64_t x1, bool& mism) -> uint32_t {
-                const uint2 inf = *reinterpret_cast<const uint2*>(T.tab + (size_t)(i * L + opos) * 32u + c8);
+                const uint32_t inf_off = (i * L + opos) * 32u + c8;
+                const uint2 inf = info_lds ? *reinterpret_cast<const uint2*>(smem + inf_off) : *reinterpret_cast<const uint2*>(T.tab + inf_off);
                 const uint32_t ent_off = inf.x, nq = inf.y;
                 const uint32_t idx = alias_index32(x1, nq);
                 uint32_t e0, e1, qp;
