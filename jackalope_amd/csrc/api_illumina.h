@@ -288,24 +288,27 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     return max_lanes;
 }
 
-// The 2-bit copy of the (final) sequence buffer and its flags: GenomeDev::packed.  Made with JK_PACKED_REF=1 only: the
-// generator is bound by instruction issue, not by the reference loads, and with the copy it is 2-5 % SLOWER at every genome
-// size tried (100 Mbp / 1 Gbp / 3 Gbp: 702 / 700 / 671 against 736 / 718 / 709 M pairs/s, tools/packed_probe.sh; it fetches
-// a quarter of the cache lines) -- so the byte path stays the default and this one stays tested.
+// The 2-bit copy of the (final) sequence buffer and its flags: GenomeDev::packed.  On by default since every source access
+// of an N-free read window goes through it (a first version that served only the 8-base gear was 2-5 % slower and fetched
+// more): same speed as the byte path at 100 Mbp / 1 Gbp / 3 Gbp and on the haplotype workload (751 / 737 / 716 / 669 against
+// 753 / 744 / 717 / 673 M pairs/s, tools/packed_probe.sh) with 37 % less fetched per launch (FETCH_SIZE 1.44 against 2.27 GB,
+// profiles/r02_pmc_packed_vs_bytes.txt).  JK_PACKED_REF=0: bytes only.
 static void pack_reference(jk_session& s) {
     if (s.d_packed.p) return;
-    const char* e = std::getenv("JK_PACKED_REF");
-    if (!e || std::atoi(e) == 0) return;
+    if (const char* e = std::getenv("JK_PACKED_REF")) if (std::atoi(e) == 0) return;
     PhaseTimer pt("packed reference");
     const uint64_t n = s.d_seq.n;
-    const uint64_t n_threads = (n + 15) / 16, n_waves = (n_threads + 63) / 64;
-    s.d_packed.alloc(n_waves * 256 + 64);
-    s.d_nflags.alloc(n_waves * 2 + 64);
-    JK_HIP(hipMemset(s.d_nflags.p, 0xff, s.d_nflags.n));
-    const uint64_t blocks = (n_threads + 255) / 256;
-    if (blocks > 0x7fffffffULL) { s.d_packed.release(); s.d_nflags.release(); return; }
+    const uint64_t n_threads = (n + 15) / 16, blocks = (n_threads + 255) / 256;
+    if (blocks > 0x7fffffffULL) return;
+    s.d_packed.alloc(blocks * 1024 + 64);
+    s.d_nflags.alloc((blocks / 32 + 3) * 4);
+    JK_HIP(hipMemset(s.d_nflags.p, 0, s.d_nflags.n));
+    // the cells of the buffer: chromosomes, or the materialised (haplotype, chromosome) sequences
+    const bool cells = s.hap && s.hap_materialised;
+    const uint64_t* len = cells ? s.d_cell_size.as<uint64_t>() : s.d_chrom_len.as<uint64_t>();
+    const uint32_t n_cells = (uint32_t)((cells ? s.d_cell_size.n : s.d_chrom_len.n) / 8);
     hipLaunchKernelGGL(pack_reference_kernel, dim3((uint32_t)blocks), dim3(256), 0, 0, s.d_seq.as<uint8_t>(), n,
-                       s.d_packed.as<uint32_t>(), s.d_nflags.as<uint16_t>());
+                       s.d_packed.as<uint32_t>(), s.d_nflags.as<uint32_t>(), s.d_chrom_off.as<uint64_t>(), len, n_cells);
     JK_HIP(hipGetLastError());
     JK_HIP(hipDeviceSynchronize());
 }

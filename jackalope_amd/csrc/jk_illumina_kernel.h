@@ -53,9 +53,9 @@ struct GenomeDev {
     const uint32_t* hdr_off;     // [n_chroms + 1]
     uint32_t n_chroms;
     // Illumina, optional (null: bytes only): the same bases at 2 bits each -- base i in bits 2*(i & 3) of packed[i >> 2],
-    // code as in seq -- and one flag bit per 64 bases, bit (i >> 6) & 7 of nflags[i >> 9], set when the 64 hold a byte that
-    // is not T, C, A or G (pack_reference_kernel).  A read end whose source window touches no flagged block takes its
-    // 8-base blocks from `packed` (one 4-byte load per block, a quarter of the cache lines); any other reads `seq`.
+    // code as in seq -- and one flag bit per 4096 bases, bit (i >> 12) & 7 of nflags[i >> 15], set when a chromosome
+    // holds a byte that is not T, C, A or G there (pack_reference_kernel).  A read end whose source window touches no
+    // flagged block takes all its bases from `packed`; any other reads `seq`.
     const uint8_t* packed;
     const uint8_t* nflags;
 };
@@ -773,16 +773,20 @@ illumina_kernel(IlluminaKernelParams P) {
             asm volatile("" : "+s"(pk));
             if (!SEG && P.g.packed != nullptr && sp > bc) {
                 const uint64_t lo = coff + start, last = lo + cspace - 1;
-                const uint64_t b0 = lo >> 6;
-                const uint32_t nb = (uint32_t)((last >> 6) - b0) + 1u;
+                const uint64_t b0 = lo >> 12;
+                const uint32_t two = (last >> 12) != b0 ? 3u : 1u;        // (a window is shorter than 4096 bases: at most two blocks)
                 uint32_t fw;
                 __builtin_memcpy(&fw, P.g.nflags + (b0 >> 3), 4);
-                const uint32_t bits = (fw >> ((uint32_t)b0 & 7u)) & ((1u << (nb < 25u ? nb : 25u)) - 1u);
-                use_bytes = bits != 0u || nb > 25u || (last >> 2) >= 0xffffff00ULL;
+                const uint32_t bits = (fw >> ((uint32_t)b0 & 7u)) & two;
+                use_bytes = bits != 0u || (last >> 2) >= 0xffffff00ULL;
             }
             auto src_byte = [&](uint32_t pp) -> uint32_t {     // general path: one source base (pp >= bc)
                 if (SEG) { while (pp >= seg_end_pp) seg_enter(pp); }
-                uint32_t c = gload8(gseq + (reverse ? A - pp : A + pp));
+                uint32_t c;
+                if (!SEG && !use_bytes) {
+                    const uint64_t p = reverse ? A - pp : A + pp;
+                    c = (gload8(pk + (uint32_t)(p >> 2)) >> (2u * ((uint32_t)p & 3u))) & 3u;
+                } else c = gload8(gseq + (reverse ? A - pp : A + pp));
                 if (reverse) c ^= ((~c) >> 1) & 2u;                 // codes 0..3: ^2 (T<->A, C<->G); others stay non-TCAG
                 return c;
             };
@@ -936,12 +940,19 @@ illumina_kernel(IlluminaKernelParams P) {
                         if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) wlo = w;
                         else { A = A0; seg_end_pp = se0; seg_state = st0; seg_moved = false; nquads = 0; }    // not TCAG somewhere: the general path redoes it
                     } else {
-                        uint32_t v;
-                        v = gload32(gseq + (reverse ? A - pp - 3u : A + pp));
-                        const uint32_t rlo = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u);
-                        wlo = rlo ^ rcm;
-                        any_n = __builtin_amdgcn_ballot_w64((v & 0xfcfcfcfcu) != 0) != 0;
-                        if (any_n) nmlo = rlo & 0xfcfcfcfcu;
+                        bool n_here = false;
+                        if (!SEG && !use_bytes) {
+                            const uint64_t p0 = reverse ? A - pp - 3u : A + pp;
+                            const uint32_t v = gload32(pk + (uint32_t)(p0 >> 2));
+                            wlo = (s_lut + (reverse ? 256u : 0u))[__builtin_amdgcn_ubfe(v, 2u * ((uint32_t)p0 & 3u), 8u)];
+                        } else {
+                            const uint32_t v = gload32(gseq + (reverse ? A - pp - 3u : A + pp));
+                            const uint32_t rlo = __builtin_amdgcn_perm(0u, v, rsel & 0x03030303u);
+                            wlo = rlo ^ rcm;
+                            n_here = (v & 0xfcfcfcfcu) != 0;
+                            nmlo = rlo & 0xfcfcfcfcu;
+                        }
+                        any_n = __builtin_amdgcn_ballot_w64(n_here) != 0;
                     }
                 }
                 if (nquads) {
@@ -1098,34 +1109,28 @@ __global__ void encode_bases_kernel(uint8_t* seq, uint64_t n, uint32_t* bad) {
 }
 
 // The 2-bit copy of an encoded buffer and its "not only TCAG" flags (GenomeDev::packed / nflags).  One thread per 16
-// bases (one output dword), one wave per 1024: 64 bases = 4 neighbouring lanes, so a wave's 16 flag bits come out of
-// one ballot.  n is the buffer's length; bytes past it count as flagged.
-__global__ void __launch_bounds__(256) pack_reference_kernel(const uint8_t* seq, uint64_t n, uint32_t* packed, uint16_t* nflags) {
+// bases (one output dword), one 256-thread workgroup per 4096 bases = one flag bit (kept coarse so that the flags of a
+// 3 Gbp genome, 92 KB, stay in L2: a flag per 64 bases cost every read end a cache line of its own).  Only bytes inside
+// a chromosome (cell) count: the padding between them is 'N'.  nflags is zeroed by the caller.
+__global__ void __launch_bounds__(256) pack_reference_kernel(const uint8_t* seq, uint64_t n, uint32_t* packed, uint32_t* nflags,
+                                                             const uint64_t* cell_off, const uint64_t* cell_len, uint32_t n_cells) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // thread = 16 bases
     const uint64_t i0 = t * 16;
     uint32_t w = 0, bad = 0;
-    if (i0 + 16 <= n) {
-        const uint4 v = *reinterpret_cast<const uint4*>(seq + i0);
-        const uint32_t c[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-            bad |= c[k] & 0xfcfcfcfcu;
-            const uint32_t x = c[k] & 0x03030303u;            // codes of 4 bases, one per byte -> 8 bits
-            const uint32_t y = (x | (x >> 6)) & 0x000f000fu;
-            w |= ((y | (y >> 12)) & 0xffu) << (8u * k);
+    if (i0 < n) {
+        // the cell this group of 16 lies in (cells start at multiples of 64: a group never spans two)
+        uint32_t lo = 0, hi = n_cells;
+        while (hi - lo > 1u) { const uint32_t m = (lo + hi) >> 1; if (cell_off[m] <= i0) lo = m; else hi = m; }
+        uint64_t in_lo = 0, in_hi = 0;
+        if (n_cells && cell_off[lo] <= i0 + 15) { in_lo = cell_off[lo]; in_hi = cell_off[lo] + cell_len[lo]; }
+        for (uint32_t k = 0; k < 16 && i0 + k < n; k++) {
+            const uint32_t c = seq[i0 + k];
+            w |= (c & 3u) << (2u * k);
+            if (c > 3u && i0 + k >= in_lo && i0 + k < in_hi) bad = 1;
         }
-    } else {
-        bad = 1;
-        for (uint32_t k = 0; k < 16 && i0 + k < n; k++) w |= (uint32_t)(seq[i0 + k] & 3u) << (2u * k);
+        packed[t] = w;
     }
-    if (i0 < n) packed[t] = w;
-    const uint64_t b = __builtin_amdgcn_ballot_w64(bad != 0);
-    if ((threadIdx.x & 63u) == 0 && i0 < n) {
-        uint32_t f = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < 16; j++) f |= (((b >> (4u * j)) & 0xfULL) != 0 ? 1u : 0u) << j;
-        nflags[t >> 6] = (uint16_t)f;
-    }
+    if (__syncthreads_or((int)bad) && threadIdx.x == 0) atomicOr(&nflags[blockIdx.x >> 5], 1u << (blockIdx.x & 31u));
 }
 
 // ---------------------------------------------------------------------------------------------
