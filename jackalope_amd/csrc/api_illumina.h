@@ -300,6 +300,11 @@ static void pack_reference(jk_session& s) {
     const uint64_t n = s.d_seq.n;
     const uint64_t n_threads = (n + 15) / 16, blocks = (n_threads + 255) / 256;
     if (blocks > 0x7fffffffULL) return;
+    {   // an extra, not a need: a run that has filled the device with pools and image goes without it
+        size_t free_b = 0, total_b = 0;
+        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        if ((uint64_t)free_b < blocks * 1024 + (2ULL << 30)) return;
+    }
     s.d_packed.alloc(blocks * 1024 + 64);
     s.d_nflags.alloc((blocks / 32 + 3) * 4);
     JK_HIP(hipMemset(s.d_nflags.p, 0, s.d_nflags.n));
