@@ -148,11 +148,20 @@ constexpr uint32_t TILE_ROW = 64 * 4;      // bytes between consecutive words of
 __device__ __forceinline__ uint8_t* os_word(uint8_t* col, uint32_t pos) { return col + (size_t)(pos >> 2) * TILE_ROW; }
 __device__ __forceinline__ void os_begin(OutStream& s, uint32_t pos) { s.pos = pos; s.acc = 0; }
 // 1..4 bytes at once (low byte first; the bytes of `word` above the n-th must be zero)
+// A word of FASTQ into the pool.  (-DJK_NT_STORES: as a non-temporal store -- the pools are written once and read back by the
+// compaction long after they have left L2, where they only push out the reference lines the generator re-reads.)
+__device__ __forceinline__ void pool_store(uint8_t* p, uint32_t w) {
+#ifdef JK_NT_STORES
+    __builtin_nontemporal_store(w, reinterpret_cast<uint32_t*>(p));
+#else
+    *reinterpret_cast<uint32_t*>(p) = w;
+#endif
+}
 __device__ __forceinline__ void os_put_n(OutStream& s, uint8_t* col, uint32_t word, uint32_t n) {
     const uint32_t cnt = s.pos & 3u;
     const uint64_t t = (uint64_t)word << (8u * cnt);
     const uint32_t w = s.acc | (uint32_t)t;
-    if (cnt + n >= 4u) { *reinterpret_cast<uint32_t*>(os_word(col, s.pos)) = w; s.acc = (uint32_t)(t >> 32); }
+    if (cnt + n >= 4u) { pool_store(os_word(col, s.pos), w); s.acc = (uint32_t)(t >> 32); }
     else s.acc = w;
     s.pos += n;
 }
@@ -821,8 +830,8 @@ illumina_kernel(IlluminaKernelParams P) {
             uint8_t* wpb = os_word(col, o.pos); uint8_t* wpq = os_word(col, oq.pos);
             auto put_quad = [&](uint32_t gb, uint32_t gq) {
                 const uint64_t tb = (uint64_t)gb << sh_b, tq = (uint64_t)gq << sh_q;
-                *reinterpret_cast<uint32_t*>(wpb) = acc_b | (uint32_t)tb; acc_b = (uint32_t)(tb >> 32); wpb += TILE_ROW;
-                *reinterpret_cast<uint32_t*>(wpq) = acc_q | (uint32_t)tq; acc_q = (uint32_t)(tq >> 32); wpq += TILE_ROW;
+                pool_store(wpb, acc_b | (uint32_t)tb); acc_b = (uint32_t)(tb >> 32); wpb += TILE_ROW;
+                pool_store(wpq, acc_q | (uint32_t)tq); acc_q = (uint32_t)(tq >> 32); wpq += TILE_ROW;
             };
             // one quality + mismatch step (IlluminaQualityError::fill_read_qual, hts_illumina.h:243-256) for a TCAG
             // base with code c (c8 = 8*c) at output position `opos`: returns 8 * quality character, sets `mism`
