@@ -263,7 +263,7 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     // workload: 1 set 15.1 ms per step, 2 sets 14.7, 3 sets 14.7 -- two is the default (JK_POOL_SETS=1/3 to change).
     s.n_pool_sets = 2;
     for (uint32_t e = 0; e < s.n_ends; e++) s.d_pool[2][e].release();
-    int want_sets = 2;
+    int want_sets = s.pacbio ? 3 : 2;      // (PacBio launches overlap: the third set lets launch b + 1 start while the compaction of b - 1 waits for slots)
     if (const char* e = std::getenv("JK_POOL_SETS")) want_sets = std::atoi(e);
     if (want_sets <= 1) s.n_pool_sets = 1;
     if (s.batches.size() > 2 && want_sets >= 3) {

@@ -104,15 +104,19 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
             Q.pool = s.d_pool[pp][0].as<uint8_t>();
             Q.lane_bytes = s.d_lane_bytes[0].as<uint64_t>() + B.lane0;
             Q.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
-            if (b >= ns) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - ns], 0));
-            JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+            const bool odd = s.two_gen_streams && (b & 1);
+            hipStream_t pgs = odd ? s.stream2 : s.stream;       // (launches two apart share their scratch: same stream, in order)
+            if (s.two_gen_streams && b == 1) JK_HIP(hipStreamWaitEvent(s.stream2, s.events[0], 0));
+            if (b >= ns) JK_HIP(hipStreamWaitEvent(pgs, s.cp_done[b - ns], 0));
+            JK_HIP(hipEventRecord(s.events[ev++], pgs));
             const uint32_t pgrid = (B.n_lanes + PB_BLOCK - 1) / PB_BLOCK;
-            Q.xchg = s.d_pb_xchg.as<uint32_t>();
-            if (s.hap) hipLaunchKernelGGL((pacbio_kernel<true>), dim3(pgrid), dim3(PB_BLOCK), PB_LDS_BYTES, s.stream, Q);
-            else hipLaunchKernelGGL((pacbio_kernel<false>), dim3(pgrid), dim3(PB_BLOCK), PB_LDS_BYTES, s.stream, Q);
+            Q.xchg = (odd ? s.d_pb_xchg_b : s.d_pb_xchg).as<uint32_t>();
+            if (odd) { Q.ev = s.d_ev2_b.as<uint64_t>(); Q.hist = s.d_pb_hist_b.as<uint64_t>(); }
+            if (s.hap) hipLaunchKernelGGL((pacbio_kernel<true>), dim3(pgrid), dim3(PB_BLOCK), PB_LDS_BYTES, pgs, Q);
+            else hipLaunchKernelGGL((pacbio_kernel<false>), dim3(pgrid), dim3(PB_BLOCK), PB_LDS_BYTES, pgs, Q);
             JK_HIP(hipGetLastError());
-            JK_HIP(hipEventRecord(s.events[ev++], s.stream));
-            JK_HIP(hipEventRecord(s.gen_done[b], s.stream));
+            JK_HIP(hipEventRecord(s.events[ev++], pgs));
+            JK_HIP(hipEventRecord(s.gen_done[b], pgs));
             if (sc && b >= 2 && !sc->wait_consumed((int)b - 2)) { stopped = true; break; }
             JK_HIP(hipStreamWaitEvent(s.cp_stream, s.gen_done[b], 0));
             const uint32_t nbp = (B.n_lanes + SCAN_BLOCK - 1) / SCAN_BLOCK;

@@ -154,6 +154,21 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     P.ev = s.d_ev2.as<uint64_t>(); P.ev_words = s.ev_words;
     s.d_pb_hist.alloc((size_t)2 * PB_HIST * std::max<uint32_t>(max_lanes, 1) * 8);
     s.d_pb_xchg.alloc((size_t)PB_XCHG_WORDS * align_up(std::max<uint32_t>(max_lanes, 1), PB_BLOCK) * 4);
+    // Overlapping launches.  The workgroups of a launch end 21 to 29 ms after its start (their lanes' reads differ in
+    // length) and a launch has exactly as many workgroups as the device has slots: with one launch at a time a seventh
+    // of the slots idle.  With a third pool set, odd launches go to a second stream with their own event / history /
+    // exchange scratch, so the next launch's workgroups move in as this one's retire; the compaction (lowest priority)
+    // takes the slots that no generator workgroup is waiting for.  JK_PB_OVERLAP=0: one launch at a time.
+    s.two_gen_streams = s.n_pool_sets >= 3 && s.batches.size() > 1;
+    if (const char* e = std::getenv("JK_PB_OVERLAP")) if (std::atoi(e) == 0) s.two_gen_streams = false;
+    if (s.two_gen_streams) {
+        s.d_ev2_b.alloc(s.d_ev2.n); s.d_pb_hist_b.alloc((size_t)2 * PB_HIST * std::max<uint32_t>(max_lanes, 1) * 8); s.d_pb_xchg_b.alloc(s.d_pb_xchg.n);
+        if (!s.stream2) {
+            int least = 0, greatest = 0;
+            JK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            JK_HIP(hipStreamCreateWithPriority(&s.stream2, hipStreamNonBlocking, greatest));
+        }
+    }
     JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pacbio_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PB_LDS_BYTES));
     JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pacbio_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PB_LDS_BYTES));
     P.hist = s.d_pb_hist.as<uint64_t>();

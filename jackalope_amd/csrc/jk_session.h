@@ -42,6 +42,7 @@ struct jk_session {
     bool streaming = false;    // batches' images go to the sink as they complete (one-shot entry points); no resident image
     PacbioKernelParams kpb{};
     DevBuf d_len_thresh, d_len_alias, d_lens, d_thr_tab, d_pass_tab, d_ev2, d_pb_hist, d_pb_xchg;
+    DevBuf d_ev2_b, d_pb_hist_b, d_pb_xchg_b;      // PacBio: second set of per-launch scratch (launches overlap, see launch_batches)
     uint32_t ev_words = 0;
     uint64_t nuc_base = 0;     // offset of the haplotypes' nucleotide blob inside d_seq
     double pool_scale = 1.25;  // PacBio: pool capacity relative to the expected bytes (grown on overflow)

@@ -14,6 +14,9 @@ cp = [k for k in ks if "compact_linear" in k[2]][-8:]
 print("generator launches (ms):", " ".join("%.1f" % ((k[1] - k[0]) / 1e6) for k in gen))
 print("compactions (ms):       ", " ".join("%.1f" % ((k[1] - k[0]) / 1e6) for k in cp))
 print("step (first generator start to last compaction end): %.1f ms" % ((cp[-1][1] - gen[0][0]) / 1e6))
+t0 = gen[0][0]
+print("generator start-end (ms):", " ".join("%.0f-%.0f" % ((k[0] - t0) / 1e6, (k[1] - t0) / 1e6) for k in gen))
+print("compaction start-end (ms):", " ".join("%.0f-%.0f" % ((k[0] - t0) / 1e6, (k[1] - t0) / 1e6) for k in cp))
 PY
 grep -o '"value": [0-9.]*' "$out/bench.log" | head -1 >> "$root/gpurun_out/ktrace_pb_$tag.txt"
 rm -rf "$out"
