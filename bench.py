@@ -377,7 +377,10 @@ def pacbio_main(a):
                "gbases_per_sec": round(total_bytes[0] / 2 * a.steps / elapsed / 1e9, 2),
                "roofline": {"bound": "hbm", "achieved": round(alg / kern_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(alg / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "pacbio_kernel<ref>",
-                            "launches_per_step": n_launch, "kernel_ms": round(kern_s * 1e3, 3)}}
+                            "launches_per_step": n_launch, "kernel_ms": round(kern_s * 1e3, 3),
+                            "note": "consecutive launches overlap (the next one's workgroups move in as this one's retire): kernel_ms = "
+                                    "time of a step with a generator launch running / launches; rocprof's per-launch durations "
+                                    "include the time a launch's workgroups wait for slots"}}
         if not a.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O

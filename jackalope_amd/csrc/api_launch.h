@@ -230,9 +230,19 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
     s.reads_made = result[3];
     float t = 0;
     double gen = 0, rest = 0;
-    for (size_t b = 0; b < s.batches.size(); b++) {
-        JK_HIP(hipEventElapsedTime(&t, s.events[1 + 2 * b], s.events[2 + 2 * b]));
-        gen += t;
+    {   // time with a generator launch running: the union of the launches' spans (PacBio launches overlap)
+        std::vector<std::pair<float, float>> span(s.batches.size());
+        for (size_t b = 0; b < s.batches.size(); b++) {
+            JK_HIP(hipEventElapsedTime(&span[b].first, s.events[0], s.events[1 + 2 * b]));
+            JK_HIP(hipEventElapsedTime(&span[b].second, s.events[0], s.events[2 + 2 * b]));
+        }
+        std::sort(span.begin(), span.end());
+        float hi = -1.0f;
+        for (const auto& sp : span) {
+            const float a = std::max(sp.first, hi);
+            if (sp.second > a) gen += sp.second - a;
+            hi = std::max(hi, sp.second);
+        }
     }
     JK_HIP(hipEventElapsedTime(&t, s.events[0], s.events[ev - 1]));
     rest = t - gen;
