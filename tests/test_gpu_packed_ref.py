@@ -1,7 +1,8 @@
 """GPU: the 2-bit copy of the reference (GenomeDev::packed, csrc/jk_illumina_kernel.h) against the byte path and the
-oracle.  A read end takes its 8-base blocks from the packed copy unless its source window touches a 64-base block that
-holds a byte other than T, C, A, G; JK_PACKED_REF=0 switches the copy off.  Every case runs both ways and is compared
-with the oracle byte for byte (src/ref_classes.h:38-39 stores one char per base: the packing is this path's own)."""
+oracle.  A read end takes all its bases from the packed copy unless its source window touches a 4096-base block in which
+a chromosome holds a byte other than T, C, A, G; JK_PACKED_REF=0 switches the copy off.  Every case runs both ways and
+is compared with the oracle byte for byte (src/ref_classes.h:38-39 stores one char per base: the packing is this path's
+own).  Chromosomes here are long enough for unflagged blocks to exist next to flagged ones."""
 import numpy as np
 import pytest
 
