@@ -23,6 +23,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+XDEV = "cuda"
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # Lanes per GPU: a generator launch takes 224 workgroups of 1024 lanes (the other 32 CUs run the compaction of the
 # launch before), the first launch of a step all 256; four launches per step, 10.5 pairs per lane on
@@ -269,12 +270,22 @@ def dist_setup(a):
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with that many ranks" % a.gpus)
         a.gpus = world
+    # Rehearsal of the N > 1 code path on a box with one GPU: JK_BENCH_ONE_DEVICE=1 puts every rank on device 0 and
+    # JK_BENCH_BACKEND=gloo replaces RCCL (which wants a device per rank) for the few integers the ranks exchange.
+    if os.environ.get("JK_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    global XDEV
+    backend = os.environ.get("JK_BENCH_BACKEND", "nccl")
+    XDEV = "cuda" if backend == "nccl" else "cpu"          # where the exchanged integers live
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("JK_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world, use_dist
 
 
@@ -300,7 +311,7 @@ def timed_steps(a, sess, use_dist):
         all_ms += tm["total"]
     sync()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=XDEV)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     return float(tmax.item()), gen_ms, all_ms
@@ -359,10 +370,10 @@ def pacbio_main(a):
     words = ja.seed_words(12345, 16 * lanes)
     sess = open_shard(lambda lo, hi, off: ja.pacbio(genome, None, n_reads, n_threads=lanes, seed_words=words, custom_read_lengths=lens,
                                                     device=local_rank, lane_begin=lo, lane_end=hi, seed_offset_words=off, _session=True),
-                      lanes, n_reads, 8, device="cuda" if use_dist else None)
+                      lanes, n_reads, 8, device=XDEV if use_dist else None)
     elapsed, gen_ms, all_ms = timed_steps(a, sess, use_dist)
     sizes, reads = sess.sizes()
-    offsets, (total_reads, total_bytes) = exchange_counts(reads, sizes, device="cuda")
+    offsets, (total_reads, total_bytes) = exchange_counts(reads, sizes, device=XDEV)
     if rank == 0:
         n_launch = max(sess.n_batches(), 1)
         alg = (sizes[0] + sizes[0] // 2) / n_launch                  # FASTQ bytes (~2 per base) + 1 reference byte per base
@@ -422,11 +433,11 @@ def hap_main(a):
     t0 = time.perf_counter()
     sess = open_shard(lambda lo, hi, off: ja.illumina(hs, None, n_reads, 150, True, n_threads=lanes, seed_words=words, device=local_rank,
                                                       lane_begin=lo, lane_end=hi, seed_offset_words=off, _session=True),
-                      lanes, n_reads // 2, 8 + 16 * n_haps, device="cuda" if use_dist else None)
+                      lanes, n_reads // 2, 8 + 16 * n_haps, device=XDEV if use_dist else None)
     open_s = time.perf_counter() - t0
     elapsed, gen_ms, all_ms = timed_steps(a, sess, use_dist)
     sizes, reads = sess.sizes()
-    offsets, (total_reads, total_bytes) = exchange_counts(reads, sizes, device="cuda")
+    offsets, (total_reads, total_bytes) = exchange_counts(reads, sizes, device=XDEV)
     if rank == 0:
         n_launch = max(sess.n_batches(), 1)
         alg = (sum(sizes) + 300 * (reads // 2)) / n_launch
@@ -488,7 +499,7 @@ def main():
     words = ja.seed_words(12345, 16 * total_lanes)
     sess = open_shard(lambda lo, hi, off: ja.illumina(genome, None, n_reads, read_length, True, n_threads=total_lanes, seed_words=words,
                                                       device=local_rank, lane_begin=lo, lane_end=hi, seed_offset_words=off, _session=True),
-                      total_lanes, n_reads // 2, 8, device="cuda" if use_dist else None)
+                      total_lanes, n_reads // 2, 8, device=XDEV if use_dist else None)
     elapsed, gen_ms, all_ms = timed_steps(a, sess, use_dist)
 
     sizes, reads_made = sess.sizes()
@@ -497,7 +508,7 @@ def main():
 
     # the path's only exchanges: the seed-offset all-gather inside open_shard and, here, per-rank {reads, bytes R1,
     # bytes R2} all-gathered over RCCL -> file offsets and totals
-    offsets, (total_reads, total_bytes) = exchange_counts(reads_made, sizes, device="cuda")
+    offsets, (total_reads, total_bytes) = exchange_counts(reads_made, sizes, device=XDEV)
     total_pairs = total_reads // 2
 
     if rank == 0:
