@@ -94,29 +94,33 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
         }
         out_cap = sc ? s.img_cap : s.out_cap;
         if (s.pacbio) {
+            // plan kernel on the generator stream, lane scan + emit kernel on the second one: the plan kernel of launch
+            // b + 1 runs beside the emit kernel of launch b, each with its own set of records / masks / counters
+            const int set = (int)(b & 1);
             PacbioKernelParams Q = s.kpb;
             Q.n_lanes = B.n_lanes;
             Q.seeds = s.d_seeds.as<uint32_t>() + B.lane0 * 8;
             Q.lane_reads = s.d_lane_reads.as<uint64_t>() + B.lane0;
             Q.chrom_reads = s.d_chrom_reads.as<uint32_t>() + B.lane0;
             Q.chrom_stride = (uint32_t)s.n_shard;
-            Q.pool_off = s.d_pool_off.as<uint64_t>() + s.batch_pool_off_index[b];
-            Q.pool = s.d_pool[pp][0].as<uint8_t>();
+            Q.rec_off = s.d_pb_rec_off.as<uint64_t>() + B.lane0;
+            Q.recs = s.d_pb_recs[set].as<PbRead>();
             Q.lane_bytes = s.d_lane_bytes[0].as<uint64_t>() + B.lane0;
             Q.lane_made = s.d_lane_made.as<uint64_t>() + B.lane0;
-            const bool odd = s.two_gen_streams && (b & 1);
-            hipStream_t pgs = odd ? s.stream2 : s.stream;       // (launches two apart share their scratch: same stream, in order)
-            if (s.two_gen_streams && b == 1) JK_HIP(hipStreamWaitEvent(s.stream2, s.events[0], 0));
-            if (b >= ns) JK_HIP(hipStreamWaitEvent(pgs, s.cp_done[b - ns], 0));
-            JK_HIP(hipEventRecord(s.events[ev++], pgs));
-            const uint32_t pgrid = (B.n_lanes + PB_BLOCK - 1) / PB_BLOCK;
-            Q.xchg = (odd ? s.d_pb_xchg_b : s.d_pb_xchg).as<uint32_t>();
-            if (odd) { Q.ev = s.d_ev2_b.as<uint64_t>(); Q.hist = s.d_pb_hist_b.as<uint64_t>(); }
-            if (s.hap) hipLaunchKernelGGL((pacbio_kernel<true>), dim3(pgrid), dim3(PB_BLOCK), PB_LDS_BYTES, pgs, Q);
-            else hipLaunchKernelGGL((pacbio_kernel<false>), dim3(pgrid), dim3(PB_BLOCK), PB_LDS_BYTES, pgs, Q);
+            Q.masks = s.d_pb_masks[set].as<uint4>();
+            Q.mask_ctr = s.d_pb_ctr[set].as<unsigned long long>();
+            Q.stale = s.d_pb_stale[set].as<uint8_t>();
+            Q.stale_ctr = s.d_pb_ctr[set].as<uint32_t>() + 2;
+            if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));      // the set is free once its emit kernel is done
+            JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+            JK_HIP(hipMemsetAsync(s.d_pb_recs[set].p, 0, std::max<uint64_t>(B.n_reads, 1) * sizeof(PbRead), s.stream));
+            JK_HIP(hipMemsetAsync(s.d_pb_ctr[set].p, 0, 16, s.stream));
+            const uint32_t pgrid = (B.n_lanes + PB_PLAN_BLOCK - 1) / PB_PLAN_BLOCK;
+            if (s.hap) hipLaunchKernelGGL((pb_plan_kernel<true>), dim3(pgrid), dim3(PB_PLAN_BLOCK), 0, s.stream, Q);
+            else hipLaunchKernelGGL((pb_plan_kernel<false>), dim3(pgrid), dim3(PB_PLAN_BLOCK), 0, s.stream, Q);
             JK_HIP(hipGetLastError());
-            JK_HIP(hipEventRecord(s.events[ev++], pgs));
-            JK_HIP(hipEventRecord(s.gen_done[b], pgs));
+            JK_HIP(hipEventRecord(s.events[ev++], s.stream));
+            JK_HIP(hipEventRecord(s.gen_done[b], s.stream));
             if (sc && b >= 2 && !sc->wait_consumed((int)b - 2)) { stopped = true; break; }
             JK_HIP(hipStreamWaitEvent(s.cp_stream, s.gen_done[b], 0));
             const uint32_t nbp = (B.n_lanes + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -124,13 +128,20 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
             uint64_t* lo = s.d_lane_off[0].as<uint64_t>() + B.lane0;
             uint64_t* bs = s.d_block_sums.as<uint64_t>();
             uint64_t* base = s.d_base[0].as<uint64_t>() + b;
-            if (b + 1 < s.batches.size()) hipLaunchKernelGGL(pb_delay_kernel, dim3(1), dim3(64), 0, s.cp_stream, (uint64_t)100000);   // 1 ms
             hipLaunchKernelGGL(scan_block_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lb, lo, bs, B.n_lanes);
             hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s.cp_stream, bs, nbp, base);
             hipLaunchKernelGGL(scan_add_kernel, dim3(nbp), dim3(SCAN_BLOCK), 0, s.cp_stream, lo, bs, B.n_lanes);
-            hipLaunchKernelGGL(compact_linear_kernel, dim3(B.n_lanes), dim3(256), 0, s.cp_stream,
-                               s.d_pool[pp][0].as<uint8_t>(), Q.pool_off, lb, lo, out_img[0], out_base[0], B.n_lanes,
-                               out_cap, s.d_err.as<uint32_t>());
+            PbEmitParams E;
+            E.g = Q.g; E.h = Q.h; E.n_chroms = s.n_chroms;
+            E.recs = Q.recs; E.n_recs = (uint32_t)B.n_reads;
+            E.seeds = Q.seeds; E.lane_off = lo;
+            E.masks = Q.masks; E.stale = Q.stale; E.jump = Q.jump;
+            E.out = out_img[0]; E.out_base = out_base[0]; E.out_cap = out_cap;
+            E.err = s.d_err.as<uint32_t>();
+            if (B.n_reads) {
+                if (Q.hap_seg) hipLaunchKernelGGL((pb_emit_kernel<true>), dim3((uint32_t)B.n_reads), dim3(64), 0, s.cp_stream, E);
+                else hipLaunchKernelGGL((pb_emit_kernel<false>), dim3((uint32_t)B.n_reads), dim3(64), 0, s.cp_stream, E);
+            }
             JK_HIP(hipGetLastError());
             JK_HIP(hipEventRecord(s.cp_done[b], s.cp_stream));
             if (sc) sc->push((int)b);
@@ -215,7 +226,7 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
     const uint32_t err = (uint32_t)result[0];
     if (err & JK_KERR_GAMMA_MATH) throw Error(JK_ERR_UNSUPPORTED, "a fragment-length draw with frag_len_shape < 1 needed pow() beyond the range implemented on the GPU (|log(u) / shape| >= 512)");
     if (err & JK_KERR_PB_MATH) throw Error(JK_ERR_UNSUPPORTED, "a PacBio parameter led to an exp/pow argument outside the range implemented on the GPU");
-    if (err & JK_KERR_PB_TOO_LONG) throw Error(JK_ERR_UNSUPPORTED, "a read was longer than the GPU path's cap (9 sigma of the log-normal, or it needed > 2x its length in reference positions)");
+    if (err & JK_KERR_PB_TOO_LONG) throw Error(JK_ERR_UNSUPPORTED, "a read was longer than 2^30 bases or needed more than twice its length in reference positions (deletion probability too high for the GPU path)");
     if (err & JK_KERR_PB_SPACE) throw Error(JK_ERR_UNSUPPORTED, "a read position lies outside the reference's read buffer (undefined there: a read as long as its chromosome or a clipped duplicate with no earlier, longer read on its thread) or needs more chromosome than there is");
     // PacBio images are sized for the expected read length (the pools' worst case would not fit): a length model whose
     // realised mean is above that (e.g. min_read_length cutting off most of the log-normal) gets a larger image

@@ -11,8 +11,8 @@ struct PacbioHostModel {
     std::vector<uint64_t> len_thresh; std::vector<uint32_t> len_alias; std::vector<uint64_t> lens;
     std::vector<double> thr_tab; std::vector<PassEntry> pass_tab;
     double min_exp = 0;
-    uint64_t len_hi = 0;      // pool sizing: a read length few reads exceed
-    uint64_t len_cap = 0;     // hard cap (event scratch)
+    uint64_t len_hi = 0;      // a read length few reads exceed
+    uint64_t len_cap = 0;     // the longest read there can be
     double len_mean = 0;      // expected read length (sizes the FASTQ image)
 };
 
@@ -36,9 +36,9 @@ static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a
         P.ln_mu = std::log(a.scale); P.ln_sigma = a.sigma; P.ln_loc = a.loc;
         P.min_read_len = std::ceil(a.min_read_len);
         if (P.min_read_len < 1) P.min_read_len = 1;
-        const double hi = std::exp(P.ln_mu + 4.0 * a.sigma) + a.loc, cap = std::exp(P.ln_mu + 9.0 * a.sigma) + a.loc;
+        const double hi = std::exp(P.ln_mu + 4.0 * a.sigma) + a.loc;
         M.len_hi = (uint64_t)std::max(hi, P.min_read_len + 1.0);
-        M.len_cap = (uint64_t)std::max(cap, P.min_read_len + 1.0);
+        M.len_cap = ~0ULL;        // a log-normal read is as long as it is drawn (and at most its chromosome, below)
         M.len_mean = std::max(std::exp(P.ln_mu + 0.5 * a.sigma * a.sigma) + a.loc, P.min_read_len);
     } else {
         if (!a.read_probs || !a.read_lens) throw Error(JK_ERR_ARG, "Probability and read lengths vector should be the same length.");
@@ -125,23 +125,107 @@ static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a
     return M;
 }
 
+// Launches (batches of whole 64-lane tiles), the image, and the scratch the two kernels hand over: read records, event
+// masks, stale characters.  Everything is sized from the EXPECTED read length; a run that outgrows its scratch or its
+// image is planned again, larger (s.pool_scale / s.image_scale, with_replan).
 static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioHostModel& M, size_t max_hdr, uint64_t max_chrom,
                           const LanePlan& lp, const QuotaModel& Q) {
+    PhaseTimer pt("pacbio: plan, alloc, upload");
     const std::vector<uint64_t>& lane_reads = lp.lane_reads;
-    // pools: sized for reads of length len_hi; the kernel checks before every record and the session retries
-    // with a larger scale if a lane ran out (s.pool_scale)
-    const uint64_t rec = max_hdr + n_digits(max_chrom) + 3 + 2 * M.len_hi + 8;
-    std::vector<uint64_t> lane_cap(s.n_shard);
-    for (uint64_t l = 0; l < s.n_shard; l++)       // per-lane regions are contiguous and hold whole 128-byte lines
-        lane_cap[l] = align_up((uint64_t)((double)(lane_reads[l] * rec) * s.pool_scale) + 2 * M.len_cap + 64, 128) + 128;
-    // the image: expected bytes (mean read length) + 12.5 % + 64 MB, not the pools' worst case (every read of maximal length)
-    uint64_t n_reads_shard = 0;
-    for (uint64_t l = 0; l < s.n_shard; l++) n_reads_shard += lane_reads[l];
-    const uint64_t image_hint = (uint64_t)((double)(n_reads_shard * (max_hdr + n_digits(max_chrom) + 3 + 2 * (uint64_t)std::ceil(M.len_mean) + 8)) * s.image_scale);
-    const uint32_t max_lanes = plan_pools_common(s, max_batch_bytes ? max_batch_bytes : (48ULL << 30), 1ULL << 18,
-                                                 lane_cap, lp, Q, image_hint);
-    s.ev_words = (uint32_t)((2 * M.len_cap + 64 + 31) / 32);
-    s.d_ev2.alloc((size_t)s.ev_words * std::max<uint32_t>(max_lanes, 1) * 8);
+    const uint64_t rec_mean = max_hdr + n_digits(max_chrom) + 3 + 2 * (uint64_t)std::ceil(M.len_mean) + 8;
+    const uint64_t batch_bytes = max_batch_bytes ? max_batch_bytes : (16ULL << 30);
+    uint64_t max_batch_lanes = 1ULL << 18;
+    if (const char* e = std::getenv("JK_BATCH_LANES")) { const long long v = std::atoll(e); if (v >= 64) max_batch_lanes = (uint64_t)v / 64 * 64; }
+    s.batches.clear(); s.batch_pool_off_index.clear();
+    std::vector<uint64_t> rec_off(std::max<uint64_t>(s.n_shard, 1), 0);
+    uint64_t max_reads = 0, total_reads = 0;
+    uint32_t max_lanes = 0;
+    for (uint64_t l = 0; l < s.n_shard;) {
+        Batch b{l, 0, 0, 0};
+        while (l < s.n_shard && b.n_lanes < max_batch_lanes) {
+            const uint64_t tl = std::min<uint64_t>(64, s.n_shard - l);
+            uint64_t r = 0;
+            for (uint64_t k = 0; k < tl; k++) r += lane_reads[l + k];
+            if (b.n_lanes > 0 && (b.n_reads + r) * rec_mean > batch_bytes) break;
+            for (uint64_t k = 0, at = b.n_reads; k < tl; k++) { rec_off[l + k] = at; at += lane_reads[l + k]; }
+            b.n_reads += r; b.n_lanes += (uint32_t)tl; l += tl;
+        }
+        if (b.n_reads > 0x7fffffffULL) throw Error(JK_ERR_UNSUPPORTED, "more than 2^31 reads in one launch: lower max_batch_bytes");
+        max_reads = std::max(max_reads, b.n_reads); max_lanes = std::max(max_lanes, b.n_lanes);
+        total_reads += b.n_reads;
+        s.batches.push_back(b);
+    }
+    // the image: expected bytes + 12.5 % + 64 MB (pb_emit_kernel refuses to write past it: JK_KERR_IMAGE_FULL)
+    auto image_for = [&](uint64_t reads) { const uint64_t v = (uint64_t)((double)(reads * rec_mean) * s.image_scale); return v + v / 8 + (64ULL << 20); };
+    s.out_cap = image_for(total_reads);
+    s.img_cap = image_for(max_reads);
+    // event masks: 16 bytes per 64 positions of a read's walk (about its length), taken from the arena in chunks per wave
+    const uint64_t blocks_per_read = (uint64_t)(M.len_mean * 1.15) / 64 + 2;
+    s.pb_mask_cap = (uint64_t)((double)(max_reads * blocks_per_read) * s.pool_scale) + ((uint64_t)max_lanes / 64 + 1) * PB_MASK_CHUNK;
+    s.pb_stale_cap = (uint32_t)std::min<double>((double)(1u << 30), (double)(1u << 20) * s.pool_scale);
+    const uint64_t sets = s.batches.size() > 1 ? 2 : 1;
+    {
+        size_t free_b = 0, total_b = 0;
+        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t image = s.streaming ? sets * s.img_cap : s.out_cap;
+        const uint64_t scratch = sets * (s.pb_mask_cap * 16 + max_reads * sizeof(PbRead) + s.pb_stale_cap);
+        // (buffers of an earlier plan of this session are released below before the new ones are made)
+        uint64_t held = 0;
+        for (int k = 0; k < 2; k++) held += s.d_pb_masks[k].n + s.d_pb_recs[k].n + s.d_pb_stale[k].n + s.d_img[k][0].n;
+        held += s.d_out[0].n;
+        if (image + scratch + s.n_shard * 64 > (uint64_t)free_b + held)
+            throw Error(JK_ERR_DEVICE, "this run needs " + std::to_string((image + scratch) >> 20) + " MiB of device memory (" +
+                        std::to_string(scratch >> 20) + " MiB of per-launch scratch for up to " + std::to_string(max_reads) + " reads per launch, " +
+                        std::to_string(image >> 20) + " MiB of FASTQ image) and " + std::to_string(((uint64_t)free_b + held) >> 20) +
+                        " MiB are free: lower max_batch_bytes, or split the job over more GPUs / calls");
+    }
+    for (int k = 0; k < 2; k++) { s.d_pb_masks[k].release(); s.d_pb_recs[k].release(); s.d_pb_stale[k].release(); s.d_img[k][0].release(); }
+    s.d_out[0].release();
+    s.d_seeds.upload(lp.lane_seeds);
+    s.d_lane_reads.upload(lane_reads);
+    upload_quotas(s, lp, Q);
+    s.d_pb_rec_off.upload(rec_off);
+    for (uint64_t k = 0; k < sets; k++) {
+        s.d_pb_masks[k].alloc(s.pb_mask_cap * 16);
+        s.d_pb_recs[k].alloc(std::max<uint64_t>(max_reads, 1) * sizeof(PbRead));
+        s.d_pb_stale[k].alloc(s.pb_stale_cap);
+        s.d_pb_ctr[k].alloc(16);
+    }
+    if (s.streaming) { for (uint64_t k = 0; k < sets; k++) s.d_img[k][0].alloc(s.img_cap); }
+    else s.d_out[0].alloc(s.out_cap + 64);
+    s.d_lane_bytes[0].alloc(std::max<uint64_t>(s.n_shard, 1) * 8);
+    s.d_lane_off[0].alloc(std::max<uint64_t>(s.n_shard, 1) * 8);
+    s.d_base[0].alloc((s.batches.size() + 1) * 8);
+    s.d_lane_made.alloc(std::max<uint64_t>(s.n_shard, 1) * 8);
+    JK_HIP(hipMemset(s.d_lane_made.p, 0, std::max<uint64_t>(s.n_shard, 1) * 8));
+    s.d_zero.alloc(16);
+    JK_HIP(hipMemset(s.d_zero.p, 0, 16));
+    s.progress_total = total_reads;
+    s.n_pool_sets = 2;
+    s.two_gen_streams = false;
+    s.d_block_sums.alloc((max_lanes / SCAN_BLOCK + 2) * 8);
+    s.d_err.alloc(4);
+    for (hipEvent_t e : s.events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s.gen_done) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s.cp_done) (void)hipEventDestroy(e);
+    s.events.assign(2 + 2 * s.batches.size() + 2, nullptr);
+    for (hipEvent_t& e : s.events) JK_HIP(hipEventCreate(&e));
+    s.gen_done.assign(s.batches.size(), nullptr);
+    s.cp_done.assign(s.batches.size(), nullptr);
+    for (hipEvent_t& e : s.gen_done) JK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipEvent_t& e : s.cp_done) JK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+
+    s.d_pb_hist.alloc((size_t)2 * PB_HIST * std::max<uint32_t>(max_lanes, 1) * 8);
+    {   // jump constants of the engine: the state j + 1 steps ahead is A s + G inc (engine::advance, pcg_random.hpp:419-434)
+        std::vector<uint64_t> jump(64 * 4);
+        jk_u128 a = 1, g = 0;
+        for (int j = 0; j < 64; j++) {
+            g += a; a *= PB_M;                      // a = M^(j+1), g = 1 + M + ... + M^j
+            jump[4 * j] = (uint64_t)a; jump[4 * j + 1] = (uint64_t)(a >> 64);
+            jump[4 * j + 2] = (uint64_t)g; jump[4 * j + 3] = (uint64_t)(g >> 64);
+        }
+        s.d_pb_jump.upload(jump);
+    }
     s.d_len_thresh.upload(M.len_thresh); s.d_len_alias.upload(M.len_alias); s.d_lens.upload(M.lens);
     s.d_thr_tab.upload(M.thr_tab); s.d_pass_tab.upload(M.pass_tab);
     PacbioKernelParams& P = s.kpb;
@@ -151,27 +235,11 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     P.g.hdr_blob = s.d_hdr_blob.as<uint8_t>();
     P.g.hdr_off = s.d_hdr_off.as<uint32_t>();
     P.g.n_chroms = s.n_chroms;
-    P.ev = s.d_ev2.as<uint64_t>(); P.ev_words = s.ev_words;
-    s.d_pb_hist.alloc((size_t)2 * PB_HIST * std::max<uint32_t>(max_lanes, 1) * 8);
-    s.d_pb_xchg.alloc((size_t)PB_XCHG_WORDS * align_up(std::max<uint32_t>(max_lanes, 1), PB_BLOCK) * 4);
-    // Overlapping launches.  The workgroups of a launch end 21 to 29 ms after its start (their lanes' reads differ in
-    // length) and a launch has exactly as many workgroups as the device has slots: with one launch at a time a seventh
-    // of the slots idle.  With a third pool set, odd launches go to a second stream with their own event / history /
-    // exchange scratch, so the next launch's workgroups move in as this one's retire; the compaction (lowest priority)
-    // takes the slots that no generator workgroup is waiting for.  JK_PB_OVERLAP=0: one launch at a time.
-    s.two_gen_streams = s.n_pool_sets >= 3 && s.batches.size() > 1;
-    if (const char* e = std::getenv("JK_PB_OVERLAP")) if (std::atoi(e) == 0) s.two_gen_streams = false;
-    if (s.two_gen_streams) {
-        s.d_ev2_b.alloc(s.d_ev2.n); s.d_pb_hist_b.alloc((size_t)2 * PB_HIST * std::max<uint32_t>(max_lanes, 1) * 8); s.d_pb_xchg_b.alloc(s.d_pb_xchg.n);
-        if (!s.stream2) {
-            int least = 0, greatest = 0;
-            JK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            JK_HIP(hipStreamCreateWithPriority(&s.stream2, hipStreamNonBlocking, greatest));
-        }
-    }
-    JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pacbio_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PB_LDS_BYTES));
-    JK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pacbio_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PB_LDS_BYTES));
+    P.g.packed = nullptr; P.g.nflags = nullptr;
+    P.hap_seg = (s.hap && !s.hap_materialised) ? 1u : 0u;
     P.hist = s.d_pb_hist.as<uint64_t>();
+    P.jump = s.d_pb_jump.as<uint64_t>();
+    P.mask_cap = s.pb_mask_cap; P.stale_cap = s.pb_stale_cap;
     // Outside the reference's `read` string its behaviour is undefined; by default such a read ends the run
     // (JK_ERR_UNSUPPORTED).  Opt-in: treat the byte as NUL, which is what freshly allocated string capacity holds.
     if (const char* e = std::getenv("JK_PB_UNDEFINED_AS_NUL")) P.undefined_as_nul = std::atoi(e) != 0;
@@ -241,6 +309,20 @@ static void open_pacbio_hap(jk_session& s, const jk_hap_set& hs, const jk_pacbio
     const QuotaModel Q = quota_model_hap(hs, hap_probs, 1, false);
     LanePlan lp = session_plan(s, Q, per_lane, seeds, a.seed_offset_given != 0, a.seed_offset_words, full);
     std::shared_ptr<LanePlan> plan = std::make_shared<LanePlan>(std::move(lp));
+    {   // Materialise the haplotypes when device memory allows (PacBioHaplotypes::one_read does it per thread and cell,
+        // src/hts_pacbio.cpp:523): pb_emit_kernel then reads plain sequences, one coalesced byte per position; through
+        // the tables every position is a search of its own.  Needs sum(cell sizes) bytes next to the image and scratch.
+        uint64_t mat = 64, reads_shard = 0;
+        for (uint64_t k = 0; k < n_cells; k++) mat += align_up(cell_size[k], 64) + 64;
+        for (uint64_t v : plan->lane_reads) reads_shard += v;
+        const uint64_t rec = max_hdr + 24 + 2 * (uint64_t)std::ceil(M.len_mean);
+        const uint64_t image = std::min<uint64_t>(reads_shard * rec, s.streaming ? (40ULL << 30) : ~0ULL);
+        size_t free_b = 0, total_b = 0;
+        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        bool want = mat + image + image / 4 + (12ULL << 30) <= free_b;
+        if (const char* e = std::getenv("JK_HAP_MATERIALISE")) want = std::atoi(e) != 0;
+        if (want) materialise_haplotypes(s, n_cells, cell_size);
+    }
     set_hap_params(s, s.kpb.h, (uint32_t)nh);
     const uint64_t mbb = a.max_batch_bytes;
     jk_session* sp = &s;

@@ -41,12 +41,15 @@ struct jk_session {
     bool pacbio = false;
     bool streaming = false;    // batches' images go to the sink as they complete (one-shot entry points); no resident image
     PacbioKernelParams kpb{};
-    DevBuf d_len_thresh, d_len_alias, d_lens, d_thr_tab, d_pass_tab, d_ev2, d_pb_hist, d_pb_xchg;
-    DevBuf d_ev2_b, d_pb_hist_b, d_pb_xchg_b;      // PacBio: second set of per-launch scratch (launches overlap, see launch_batches)
+    DevBuf d_len_thresh, d_len_alias, d_lens, d_thr_tab, d_pass_tab, d_pb_hist, d_pb_jump, d_pb_rec_off;
+    // PacBio, per launch in flight (pb_plan_kernel of launch b + 1 runs beside pb_emit_kernel of launch b): read records,
+    // event-mask arena, stale characters, {mask counter, stale counter}
+    DevBuf d_pb_recs[2], d_pb_masks[2], d_pb_stale[2], d_pb_ctr[2];
+    uint64_t pb_mask_cap = 0; uint32_t pb_stale_cap = 0;
     uint32_t ev_words = 0;
     uint64_t nuc_base = 0;     // offset of the haplotypes' nucleotide blob inside d_seq
-    double pool_scale = 1.25;  // PacBio: pool capacity relative to the expected bytes (grown on overflow)
-    double image_scale = 1.0;  // PacBio: image capacity relative to the expected bytes (grown when the compaction ran out of image)
+    double pool_scale = 1.25;  // PacBio: scratch capacity (event masks, stale characters) relative to the expected need (grown on overflow)
+    double image_scale = 1.0;  // PacBio: image capacity relative to the expected bytes (grown when pb_emit_kernel ran out of image)
     uint32_t retries = 0;      // re-plans of the last generate() (pool or image too small)
     std::function<void()> replan;   // PacBio: re-plan pools after pool_scale changed
     DevBuf d_bucket_off, d_bucket, d_cell_off, d_mut, d_cell_size, d_bc_blob, d_bc_len;
