@@ -210,8 +210,15 @@ __device__ __forceinline__ uint32_t pb_nt_of_char(uint32_t ch) { return ch == 'T
 // terminating NUL if it equals the string's size, and lies outside the string otherwise (undefined in the reference,
 // refused here unless undefined_as_nul).
 // ---------------------------------------------------------------------------------------------------------------
+// Four waves per SIMD (128 VGPRs; the per-lane set-up phases spill 16 of them, the shared pass-1 loop needs few): the
+// loop is a dependent chain per wave -- multiply-add, output, compares, scalar bookkeeping -- and only other waves fill
+// its gaps (measured on BASELINE configs[4]: 13.8 ms per launch against 28.9 with the 224 VGPRs the compiler would take)
+#ifndef JK_PB_PLAN_WAVES
+#define JK_PB_PLAN_WAVES 4
+#endif
+#define JK_PB_PLAN_ATTR __attribute__((amdgpu_waves_per_eu(JK_PB_PLAN_WAVES, JK_PB_PLAN_WAVES)))
 template <bool HAP>
-__global__ void __launch_bounds__(PB_PLAN_BLOCK)
+__global__ void __launch_bounds__(PB_PLAN_BLOCK) JK_PB_PLAN_ATTR
 pb_plan_kernel(PacbioKernelParams P) {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t lid = pb_lane_id();
@@ -407,10 +414,36 @@ pb_plan_kernel(PacbioKernelParams P) {
                 const jk_u128 st = Aj * S + Gj * I;                 // lane j: the state j + 1 steps ahead
                 uint32_t s0 = (uint32_t)st, s1 = (uint32_t)(st >> 32), s2 = (uint32_t)(st >> 64), s3 = (uint32_t)(st >> 96);
                 const jk_u128 C64 = PB_G64 * I;
-                const uint64_t c_lo = (uint64_t)C64, c_hi = (uint64_t)(C64 >> 64);
+                uint64_t c_lo = (uint64_t)C64, c_hi = (uint64_t)(C64 >> 64);
+                asm volatile("" : "+v"(c_lo), "+v"(c_hi));          // (kept in vector registers: the addend of v_mad_u64_u32)
                 const uint32_t Lm1 = L32 - 1u;
                 bool on_right = false;
                 for (;;) {
+                    // Blocks that need no looking at: while the current length is more than 128 short of the split (on the
+                    // left side) and of the last base, 64 spare bases remain per block and the walk's cap is far, a block is
+                    // three compares and three popcounts (the length grows by at most 128 per block, the spare chromosome
+                    // shrinks by at most 64).  The careful block below takes over wherever that ends.
+                    if (f == 0u) {
+                        uint32_t nsafe = (Lm1 - cur) >> 7;
+                        if (!on_right) { const uint32_t b_ = sp32 >= cur ? (sp32 - cur) >> 7 : 0u; nsafe = nsafe < b_ ? nsafe : b_; }
+                        { const uint32_t c_ = extra >> 6, d_ = (max_pos - upos) >> 6; nsafe = nsafe < c_ ? nsafe : c_; nsafe = nsafe < d_ ? nsafe : d_; }
+                        if (nsafe) {
+                            uint32_t si = 0, sd = 0, ss = 0;
+                            uint4* mp = P.masks + mk0 + (upos >> 6);
+                            for (uint32_t q = 0; q < nsafe; q++) {
+                                const uint64_t xq = pb_pcg_out(s0, s1, s2, s3);
+                                const uint64_t qn = __builtin_amdgcn_ballot_w64(xq >= tn), qi = __builtin_amdgcn_ballot_w64(xq < ti), qd = __builtin_amdgcn_ballot_w64(xq < td);
+                                const uint64_t ins = ~qn & qi, nd_ = ~qn & ~qi, del = nd_ & qd, sub = nd_ & ~qd;
+                                si += (uint32_t)__builtin_popcountll(ins); sd += (uint32_t)__builtin_popcountll(del); ss += (uint32_t)__builtin_popcountll(sub);
+                                const uint64_t plo_ = ins | sub, phi_ = nd_;          // (deletion or substitution: neither none nor insertion)
+                                if (lid == 0) mp[q] = make_uint4((uint32_t)plo_, (uint32_t)(plo_ >> 32), (uint32_t)phi_, (uint32_t)(phi_ >> 32));
+                                pb_pcg_mad64(s0, s1, s2, s3, c_lo, c_hi);
+                            }
+                            cur += 64u * nsafe + si - sd; extra += si - sd;
+                            n_ins += si; n_del += sd; n_sub += ss; upos += 64u * nsafe;
+                        }
+                    }
+                    if (upos >= max_pos) break;                          // (the cap is reached with the read unfinished: refused below)
                     const uint64_t x = pb_pcg_out(s0, s1, s2, s3);
                     // same decision tree as the reference (src/hts_pacbio.h:296-314) on 64 positions at once
                     uint64_t bn = (f & 1u) ? 0ULL : __builtin_amdgcn_ballot_w64(x >= tn);
@@ -418,18 +451,44 @@ pb_plan_kernel(PacbioKernelParams P) {
                     uint64_t bd = (f & 4u) ? ~0ULL : __builtin_amdgcn_ballot_w64(x < td);
                     uint64_t plo, phi;
                     uint32_t k;
-                    // a block far from everything that makes positions depend on each other -- the split (the thresholds
-                    // change when the current length reaches it), the read's end (an insertion at the last base is not
-                    // recorded), an exhausted chromosome (nor is a deletion without spare bases) -- is pure mask arithmetic
-                    const bool fast = (on_right || cur + 128u <= sp32) && cur + 128u <= Lm1 && extra >= 64u && upos + 64u <= max_pos;
-                    if (fast) {
-                        const uint64_t ins = ~bn & bi, del = ~bn & ~bi & bd, sub = ~bn & ~bi & ~bd;
+                    if (extra >= 64u && upos + 64u <= max_pos) {
+                        // Every deletion of this block finds spare chromosome, so positions depend on each other through
+                        // the current length only: it decides the side of the split (the thresholds change when it reaches
+                        // split_pos), whether an insertion is recorded (not at the last base) and where the read ends --
+                        // and before position i it is cur + i + #insertions - #deletions below i, a popcount prefix.
+                        uint64_t ins = ~bn & bi, del = ~bn & ~bi & bd, sub = ~bn & ~bi & ~bd;
+                        if (!on_right && cur + 128u > sp32) {
+                            const uint32_t len_i = cur + lid + pb_mbcnt(ins, 0u) - pb_mbcnt(del, 0u);
+                            const uint64_t m = __builtin_amdgcn_ballot_w64(len_i >= sp32);   // (exact up to its first lane: all below are left)
+                            if (m != 0) {
+                                on_right = true;
+                                tn = tnR; ti = tiR; td = tdR; f = fboth >> 8;
+                                bn = (f & 1u) ? 0ULL : __builtin_amdgcn_ballot_w64(x >= tn);
+                                bi = (f & 2u) ? ~0ULL : __builtin_amdgcn_ballot_w64(x < ti);
+                                bd = (f & 4u) ? ~0ULL : __builtin_amdgcn_ballot_w64(x < td);
+                                const uint64_t low = (m & (0ULL - m)) - 1ULL;                 // the positions still on the left
+                                ins = (ins & low) | (~bn & bi & ~low);
+                                del = (del & low) | (~bn & ~bi & bd & ~low);
+                                sub = (sub & low) | (~bn & ~bi & ~bd & ~low);
+                            }
+                        }
+                        k = 64u;
+                        if (cur + 128u > Lm1) {
+                            const uint32_t len_i = cur + lid + pb_mbcnt(ins, 0u) - pb_mbcnt(del, 0u);
+                            const uint64_t pm = __builtin_amdgcn_ballot_w64(len_i < L32);        // positions the loop reaches: a prefix
+                            // an insertion at the last base is not recorded (it can only be the last position reached)
+                            const uint64_t unrec = ins & __builtin_amdgcn_ballot_w64(len_i == Lm1);
+                            ins &= pm & ~unrec; del &= pm; sub &= pm;
+                            k = (uint32_t)__builtin_popcountll(pm);
+                        }
                         const uint32_t ni = (uint32_t)__builtin_popcountll(ins), nd = (uint32_t)__builtin_popcountll(del);
-                        cur += 64u + ni - nd; extra += ni - nd;
+                        cur += k + ni - nd; extra += ni - nd;
                         n_ins += ni; n_del += nd; n_sub += (uint32_t)__builtin_popcountll(sub);
                         plo = ins | sub; phi = del | sub;
-                        k = 64u; upos += 64u;
+                        upos += k;
                     } else {
+                        // the chromosome is nearly used up (a deletion is only recorded while spare bases remain), or the
+                        // walk is about to exceed its cap: position by position
                         plo = 0; phi = 0; k = 0;
                         while (k < 64u && cur < L32 && upos < max_pos) {
                             if (!on_right && cur >= sp32) {      // (the reference switches sides when the length reaches split_pos)
@@ -627,12 +686,23 @@ pb_plan_kernel(PacbioKernelParams P) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // pb_emit_kernel: the text of one read per wave (append_pool, src/hts_pacbio.cpp:350-414 / :417-485).
+//
+// Memory side: a wave-wide byte access costs the texture addresser as much as a wave-wide 16-byte access (the first
+// version -- one byte load and two byte stores per 64 positions -- was bound by exactly that: 70 clocks per block and
+// CU).  So the source window arrives as ONE dword per lane per 256 positions and is dealt to the position lanes through
+// the LDS crossbar (ds_bpermute), and the text is laid down byte-wise in a 2 KB LDS ring indexed by the low bits of its
+// global address and leaves as whole 1 KB-aligned segments, 16 bytes per lane.
 // SEG: the bases of a haplotype come through the mutation tables, one lookup per position (the fallback when the
 // haplotypes do not fit in device memory materialised).
 // ---------------------------------------------------------------------------------------------------------------
+constexpr uint32_t PB_RING = 2048;
+struct PbMaskBlock { uint32_t x, y, z, w; };
+typedef const PbMaskBlock __attribute__((address_space(4)))* pb_cmask_t;      // (constant address space: uniform loads become s_load)
+
 template <bool SEG>
 __global__ void __launch_bounds__(64)
 pb_emit_kernel(PbEmitParams P) {
+    __shared__ __align__(16) uint8_t ring[PB_RING];
     const uint32_t r = blockIdx.x;
     if (r >= P.n_recs) return;
     const PbRead R = P.recs[r];
@@ -647,19 +717,45 @@ pb_emit_kernel(PbEmitParams P) {
     const uint64_t at = P.out_base[0] + P.lane_off[R.lane] + R.out_off;
     // the image is allocated for the expected size: never write past it
     if (at + out_len > P.out_cap) { if (lid == 0) atomicOr(P.err, JK_KERR_IMAGE_FULL); return; }
-    uint8_t* const out = P.out + at;
+
+    // ---- the text writer: g = global address of the next byte, `flushed` = the first byte still in the ring
+    uint64_t g = (uint64_t)(uintptr_t)(P.out + at), flushed = g;
+    auto put = [&](uint32_t off, uint32_t byte) { ring[((uint32_t)g + off) & (PB_RING - 1u)] = (uint8_t)byte; };
+    // write out the ring's bytes [flushed, upto) of the 1 KB-aligned segment that holds `flushed` (upto <= its end)
+    auto flush_segment = [&](uint64_t upto) {
+        __syncthreads();
+        const uint64_t seg = flushed & ~1023ULL;
+        const uint64_t pa = seg + 16u * lid;                 // this lane's 16-byte piece
+        const uint64_t plo = pa > flushed ? pa : flushed, phi = pa + 16u < upto ? pa + 16u : upto;
+        if (plo < phi) {
+            if (phi - plo == 16u) {
+                const uint4 v = *reinterpret_cast<const uint4*>(ring + ((uint32_t)pa & (PB_RING - 1u)));
+                *reinterpret_cast<uint4*>((uintptr_t)pa) = v;
+            } else {
+                for (uint64_t a = plo; a < phi; a++) *reinterpret_cast<uint8_t*>((uintptr_t)a) = ring[(uint32_t)a & (PB_RING - 1u)];
+            }
+        }
+        flushed = upto;
+        __syncthreads();
+    };
+    auto flush_full = [&]() { while (g - (flushed & ~1023ULL) >= 1024u) flush_segment((flushed & ~1023ULL) + 1024u); };
 
     // ---- id line: "@<genome>-<chromosome>-" + start + "-F\n" / "-R\n"
-    for (uint32_t i = lid; i < hlen; i += 64u) out[i] = P.g.hdr_blob[h0 + i];
+    for (uint32_t i0 = 0; i0 < hlen; i0 += 64u) {
+        if (i0 + lid < hlen) put(lid, P.g.hdr_blob[h0 + i0 + lid]);
+        g += (hlen - i0 < 64u ? hlen - i0 : 64u);
+        flush_full();
+    }
     if (lid < nd) {
         uint64_t p10 = 1;
         for (uint32_t j = lid + 1u; j < nd; j++) p10 *= 10u;
-        out[hlen + lid] = (uint8_t)('0' + (uint32_t)((R.read_start / p10) % 10u));
+        put(lid, '0' + (uint32_t)((R.read_start / p10) % 10u));
     }
-    if (lid == 61u) out[hlen + nd] = '-';
-    if (lid == 62u) out[hlen + nd + 1u] = reverse ? 'R' : 'F';
-    if (lid == 63u) out[hlen + nd + 2u] = '\n';
-    uint8_t* const seq = out + hlen + nd + 3u;
+    if (lid == 61u) put(nd, '-');
+    if (lid == 62u) put(nd + 1u, reverse ? 'R' : 'F');
+    if (lid == 63u) put(nd + 2u, '\n');
+    g += nd + 3u;
+    flush_full();
 
     // ---- bases: 64 positions of the walk per step, one per lane
     const uint32_t* sw = P.seeds + (size_t)R.lane * 8;
@@ -667,85 +763,132 @@ pb_emit_kernel(PbEmitParams P) {
     const jk_u128 Aj = jk_mk128(P.jump[4 * lid + 1], P.jump[4 * lid]);
     const jk_u128 Cj = jk_mk128(P.jump[4 * lid + 3], P.jump[4 * lid + 2]) * I;
     jk_u128 S = jk_mk128(R.s_hi, R.s_lo);         // engine state behind the last draw handed out (wave-uniform)
-    uint64_t xbuf = 0;                            // lane j: draw number j of the current buffer of 64
+    uint32_t xb_lo = 0, xb_hi = 0;                // lane j: draw number j of the current buffer of 64
     uint32_t used = 64u;                          // draws of the buffer already handed out (64: none left)
     auto refill = [&]() {
         const jk_u128 st = Aj * S + Cj;
         const uint32_t s0 = (uint32_t)st, s1 = (uint32_t)(st >> 32), s2 = (uint32_t)(st >> 64), s3 = (uint32_t)(st >> 96);
-        xbuf = pb_pcg_out(s0, s1, s2, s3);
+        const uint64_t xv = pb_pcg_out(s0, s1, s2, s3);
+        xb_lo = (uint32_t)xv; xb_hi = (uint32_t)(xv >> 32);
         S = jk_mk128(((uint64_t)pb_rl32(s3, 63) << 32) | pb_rl32(s2, 63), ((uint64_t)pb_rl32(s1, 63) << 32) | pb_rl32(s0, 63));
     };
     const uint64_t coff = P.g.chrom_off[SEG ? R.ci % P.n_chroms : R.ci];
     const uint8_t* const gseq = P.g.seq;
     // forward: position p of the window is the byte at A + p; reverse: the complement of the one at A - p
     const uint64_t A = coff + (reverse ? R.read_start + space - 1u : R.read_start);
+    const uint32_t rcm = reverse ? 2u : 0u;
+    const uint32_t bsh = 8u * (reverse ? 3u - (lid & 3u) : (lid & 3u));      // where this lane's base sits in the dword dealt to it
+    const pb_cmask_t cmasks = (pb_cmask_t)(uintptr_t)(P.masks + R.mask_idx);
     uint32_t cur = 0;                             // bases written so far
     const uint32_t nblk = (R.n_pos + 63u) >> 6;
-    for (uint32_t b = 0; b < nblk && cur < L; b++) {
-        const uint4 mv = P.masks[R.mask_idx + b];
-        const uint64_t lo = (uint64_t)mv.x | ((uint64_t)mv.y << 32), hi = (uint64_t)mv.z | ((uint64_t)mv.w << 32);
-        const uint64_t insm = lo & ~hi, delm = hi & ~lo, keep = ~delm;
-        const uint32_t off = pb_mbcnt(insm, pb_mbcnt(keep, 0u));          // bases the positions below this lane's add
-        const uint32_t need = L - cur;
-        const uint64_t pm = __builtin_amdgcn_ballot_w64(off < need);      // positions the walk visits: a prefix of the block
-        const bool proc = off < need;
-        const uint64_t evm = lo & pm;                                     // insertions and substitutions among them: one draw each
-        const uint32_t p = b * 64u + lid;
-        const bool my_ev = (evm >> lid) & 1ULL, my_sub = my_ev && ((hi >> lid) & 1ULL);
-        const bool my_ins = my_ev && !my_sub, my_keep = (keep >> lid) & 1ULL;
-        // ---- this block's draws, in position order (src/hts_pacbio.cpp:384-395): consecutive outputs of the stream by rank
-        uint64_t x = 0;
-        if (evm != 0) {
-            const uint32_t d = used + pb_mbcnt(evm, 0u);
-            const uint32_t ne = (uint32_t)__builtin_popcountll(evm);
-            if (used + ne <= 64u) x = __shfl(xbuf, (int)(d & 63u), 64);
-            else {
-                const uint64_t x1 = __shfl(xbuf, (int)(d & 63u), 64);     // (meaningful where d < 64)
-                refill();
-                const uint64_t x2 = __shfl(xbuf, (int)((d - 64u) & 63u), 64);
-                x = d < 64u ? x1 : x2;
-                used -= 64u;
+    // the window's bytes for 256 positions: lane l holds positions 4l .. 4l+3 of the group (reverse: in descending address order)
+    auto load_group = [&](uint32_t p0) -> uint32_t {
+        uint32_t w = 0;
+        if (!SEG && p0 + 4u * lid < space) {
+            const uint8_t* a = reverse ? gseq + (A - p0 - 4u * lid - 3u) : gseq + (A + p0 + 4u * lid);
+            __builtin_memcpy(&w, a, 4);
+        }
+        return w;
+    };
+    uint32_t wsrc = load_group(0);
+    for (uint32_t b0 = 0; b0 < nblk && cur < L; b0 += 4u) {
+        const uint32_t wnext = (b0 + 4u < nblk) ? load_group((b0 + 4u) * 64u) : 0u;      // (requested a group ahead)
+        for (uint32_t q = 0; q < 4u && b0 + q < nblk && cur < L; q++) {
+            const uint32_t b = b0 + q;
+            const uint32_t mvx = cmasks[b].x, mvy = cmasks[b].y, mvz = cmasks[b].z, mvw = cmasks[b].w;
+            const uint64_t lo = (uint64_t)mvx | ((uint64_t)mvy << 32), hi = (uint64_t)mvz | ((uint64_t)mvw << 32);
+            const uint64_t insm = lo & ~hi, delm = hi & ~lo, keep = ~delm;
+            const uint32_t off = pb_mbcnt(insm, pb_mbcnt(keep, 0u));          // bases the positions below this lane's add
+            const uint32_t need = L - cur;
+            const bool proc = off < need;                                     // positions the walk visits: a prefix of the block
+            const uint64_t pm = __builtin_amdgcn_ballot_w64(proc);
+            const uint64_t evm = lo & pm;                                     // insertions and substitutions among them: one draw each
+            const uint32_t p = b * 64u + lid;
+            const bool my_ev = (evm >> lid) & 1ULL, my_sub = my_ev && ((hi >> lid) & 1ULL);
+            const bool my_ins = my_ev && !my_sub, my_keep = (keep >> lid) & 1ULL;
+            // ---- this block's draws, in position order (src/hts_pacbio.cpp:384-395): consecutive outputs of the stream by rank
+            // substitution: mm_nucleos[nt][(uint64)(runif_01 * 3)]; insertion: jlp::bases[(uint64)(runif_01 * 4)]
+            const uint32_t nidx = my_sub ? 3u : 4u;
+            uint32_t code = 0;
+            bool is_nul = false;
+            if (evm != 0) {
+                const uint32_t d = used + pb_mbcnt(evm, 0u);
+                const uint32_t ne = (uint32_t)__builtin_popcountll(evm);
+                uint32_t xh, xl = 0;
+                const bool two = used + ne > 64u;
+                uint32_t o_lo = xb_lo, o_hi = xb_hi;                          // (the old buffer, should the exact path want its low words)
+                if (!two) xh = (uint32_t)__shfl((int)xb_hi, (int)(d & 63u), 64);
+                else {
+                    const uint32_t x1 = (uint32_t)__shfl((int)xb_hi, (int)(d & 63u), 64);     // (meaningful where d < 64)
+                    refill();
+                    const uint32_t x2 = (uint32_t)__shfl((int)xb_hi, (int)((d - 64u) & 63u), 64);
+                    xh = d < 64u ? x1 : x2;
+                    used -= 64u;
+                }
+                used += ne;
+                // (uint64)(runif_01 * n) = hi32(xh * n + carry of the low word) unless the low half of xh * n is within n + 1
+                // of wrapping (2^-30 per draw): then the low word of the draw is fetched and runif_index32 decides
+                code = __umulhi(xh, nidx);
+                if (__builtin_amdgcn_ballot_w64(my_ev && xh * nidx >= 0xfffffff0u) != 0) {
+                    asm volatile("" ::: "memory");
+                    if (!two) xl = (uint32_t)__shfl((int)xb_lo, (int)(d & 63u), 64);
+                    else {
+                        const uint32_t l1 = (uint32_t)__shfl((int)o_lo, (int)(d & 63u), 64), l2 = (uint32_t)__shfl((int)xb_lo, (int)((d - 64u) & 63u), 64);
+                        xl = d < 64u ? l1 : l2;
+                    }
+                    code = runif_index32(((uint64_t)xh << 32) | xl, nidx);
+                    is_nul = my_ev && code >= nidx;                                // index past the string: its NUL
+                }
+                (void)o_hi;
             }
-            used += ne;
-        }
-        // substitution: mm_nucleos[nt][(uint64)(runif_01 * 3)]; insertion: jlp::bases[(uint64)(runif_01 * 4)]
-        const uint32_t nidx = my_sub ? 3u : 4u;
-        const uint32_t code = runif_index32(x, nidx);
-        const bool is_nul = my_ev && code >= nidx;                        // index past the string: its NUL
-        // ---- source base
-        const bool inwin = p < space;
-        uint32_t c = 0;
-        if (proc && inwin) {
+            // ---- source base
+            const bool inwin = p < space;
+            uint32_t craw = 0;
             if (SEG) {
-                const uint64_t hpos = reverse ? (R.read_start + space - 1u - p) : (R.read_start + p);
-                int64_t m = hap_search(P.h, R.ci, hpos);
-                c = gseq[hap_resolve(P.h, coff, R.ci, m, hpos).addr];
-            } else c = gseq[reverse ? A - p : A + p];
-            if (reverse && c < 4u) c ^= 2u;
+                if (proc && inwin) {
+                    const uint64_t hpos = reverse ? (R.read_start + space - 1u - p) : (R.read_start + p);
+                    int64_t m = hap_search(P.h, R.ci, hpos);
+                    craw = gseq[hap_resolve(P.h, coff, R.ci, m, hpos).addr];
+                }
+            } else {
+                const uint32_t wq = (uint32_t)__shfl((int)wsrc, (int)(16u * q + (lid >> 2)), 64);
+                craw = (wq >> bsh) & 0xffu;
+            }
+            const uint32_t c = craw ^ rcm;                                    // (complemented on the reverse strand, if it is a base)
+            uint32_t ch, ich;
+            if (__builtin_amdgcn_ballot_w64(proc && (craw >= 4u || !inwin || is_nul)) == 0) {
+                // every visited position is T, C, A or G inside the window (bytes above the lowest of a result are not stored)
+                const uint32_t sc = code + (code >= c ? 1u : 0u);
+                ch = __builtin_amdgcn_perm(0u, 0x47414354u, my_sub ? sc : c);
+                ich = __builtin_amdgcn_perm(0u, 0x47414354u, code);
+            } else {
+                // characters as the reference's `read` buffer holds them (cmp_map on the reverse strand keeps N and zeroes
+                // everything else that is not a base; positions past the window hold what earlier reads left)
+                uint32_t bch, nt;
+                if (!inwin) { bch = proc ? P.stale[R.stale_idx + (p - space)] : 0u; nt = pb_nt_of_char(bch); }
+                else if (craw < 4u) { bch = base_char(c); nt = c; }
+                else { bch = reverse ? (craw == 'N' ? (uint32_t)'N' : 0u) : jk_decode_other(craw); nt = 4u; }
+                const uint32_t sub_ch = is_nul ? 0u : (nt < 4u ? base_char(code + (code >= nt ? 1u : 0u)) : (uint32_t)'N');
+                ch = my_sub ? sub_ch : bch;
+                ich = is_nul ? 0u : base_char(code & 3u);
+            }
+            if (proc && my_keep) put(off, ch);
+            if (proc && my_ins) put(off + 1u, ich);
+            const uint32_t nb = (uint32_t)__builtin_popcountll(keep & pm) + (uint32_t)__builtin_popcountll(insm & pm);
+            cur += nb; g += nb;
+            flush_full();
         }
-        uint32_t ch, ich;
-        if (__builtin_amdgcn_ballot_w64(proc && (c >= 4u || !inwin || is_nul)) == 0) {
-            // every visited position is T, C, A or G inside the window
-            ch = my_sub ? base_char(code + (code >= c ? 1u : 0u)) : base_char(c);
-            ich = base_char(code & 3u);
-        } else {
-            // characters as the reference's `read` buffer holds them (cmp_map on the reverse strand keeps N and zeroes
-            // everything else that is not a base; positions past the window hold what earlier reads left)
-            uint32_t bch, nt;
-            if (!inwin) { bch = proc ? P.stale[R.stale_idx + (p - space)] : 0u; nt = pb_nt_of_char(bch); }
-            else if (c < 4u) { bch = base_char(c); nt = c; }
-            else { bch = reverse ? (c == 'N' ? (uint32_t)'N' : 0u) : jk_decode_other(c); nt = 4u; }
-            const uint32_t sub_ch = is_nul ? 0u : (nt < 4u ? base_char(code + (code >= nt ? 1u : 0u)) : (uint32_t)'N');
-            ch = my_sub ? sub_ch : bch;
-            ich = is_nul ? 0u : base_char(code & 3u);
-        }
-        if (proc && my_keep) seq[cur + off] = (uint8_t)ch;
-        if (proc && my_ins) seq[cur + off + 1u] = (uint8_t)ich;
-        cur += (uint32_t)__builtin_popcountll(keep & pm) + (uint32_t)__builtin_popcountll(insm & pm);
+        wsrc = wnext;
     }
-    // ---- "\n+\n", the two runs of the quality line, "\n"
-    uint8_t* const ql = seq + L + 3u;
-    if (lid == 0) { seq[L] = '\n'; seq[L + 1u] = '+'; seq[L + 2u] = '\n'; ql[L] = '\n'; }
+    // ---- "\n+\n": the rest of the ring leaves, the quality line goes straight to the image
+    if (lid == 0) put(0u, '\n');
+    if (lid == 1) put(1u, '+');
+    if (lid == 2) put(2u, '\n');
+    g += 3u;
+    flush_full();
+    if (g > flushed) flush_segment(g);
+    uint8_t* const ql = reinterpret_cast<uint8_t*>((uintptr_t)g);
+    if (lid == 0) ql[L] = '\n';
     const uint32_t q_left = (R.flags >> 8) & 0xffu, q_right = (R.flags >> 16) & 0xffu, split = R.split;
     // 16-byte pieces at 16-byte aligned addresses; the pieces at the ends and the one across the split byte by byte
     const uint32_t head = (uint32_t)((16u - ((uintptr_t)ql & 15u)) & 15u);      // bytes before the first aligned piece

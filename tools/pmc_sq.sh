@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage: tools/pmc_sq.sh <workload> <kernel-substring>   (GPU box) -- SQ counter passes for one bench workload
+# usage: tools/pmc_sq.sh <workload> <kernel-substring> [<kernel-substring> ...]   (GPU box) -- SQ counter passes for one bench workload
 set -e
-w=$1; k=$2
+w=$1; shift; k="$*"
 root=$(pwd); out=$root/gpurun_out/sq_$w; rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -10,15 +10,17 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_AN
   rocprofv3 --pmc $set -d "$out/p$i" -o p --output-format csv -- python3 "$root/bench.py" --workload $w --steps 1 --warmup 1 --no-cpu-baseline > "$out/p$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$out/p$i.log"; }
 done
 cd "$root"
-python3 - "$out" "$k" <<'PY'
+python3 - "$out" $k <<'PY'
 import csv, glob, sys, collections
-out, k = sys.argv[1], sys.argv[2]
-agg = collections.defaultdict(list)
-for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
+out, ks = sys.argv[1], sys.argv[2:]
+rows = [r for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True) for r in csv.DictReader(open(f))]
+for k in ks:
+    agg = collections.defaultdict(list)
+    for r in rows:
         if k in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for c, v in sorted(agg.items()):
-    print("%-24s n=%3d mean=%.4g" % (c, len(v), sum(v) / len(v)))
+    print("== kernels matching %r" % k)
+    for c, v in sorted(agg.items()):
+        print("%-24s n=%3d mean=%.4g" % (c, len(v), sum(v) / len(v)))
 PY
 rm -rf "$out"/p*/
