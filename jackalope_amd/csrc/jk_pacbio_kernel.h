@@ -760,24 +760,35 @@ pb_emit_kernel(PbEmitParams P) {
     // ---- bases: 64 positions of the walk per step, one per lane
     const uint32_t* sw = P.seeds + (size_t)R.lane * 8;
     const jk_u128 I = (jk_mk128(((uint64_t)sw[4] << 32) + sw[5], ((uint64_t)sw[6] << 32) + sw[7]) << 1) | 1;     // the stream's increment
-    const jk_u128 Aj = jk_mk128(P.jump[4 * lid + 1], P.jump[4 * lid]);
-    const jk_u128 Cj = jk_mk128(P.jump[4 * lid + 3], P.jump[4 * lid + 2]) * I;
-    jk_u128 S = jk_mk128(R.s_hi, R.s_lo);         // engine state behind the last draw handed out (wave-uniform)
-    uint32_t xb_lo = 0, xb_hi = 0;                // lane j: draw number j of the current buffer of 64
-    uint32_t used = 64u;                          // draws of the buffer already handed out (64: none left)
-    auto refill = [&]() {
-        const jk_u128 st = Aj * S + Cj;
-        const uint32_t s0 = (uint32_t)st, s1 = (uint32_t)(st >> 32), s2 = (uint32_t)(st >> 64), s3 = (uint32_t)(st >> 96);
-        const uint64_t xv = pb_pcg_out(s0, s1, s2, s3);
+    // The walk's draws (one per insertion / substitution, in position order): lane j keeps the engine state j + 1 steps
+    // behind the last buffer of 64 draws, so the next buffer is one multiply-add by M^64 per lane.  A draw is only ever
+    // used as (uint64)(runif_01 * 3) or (uint64)(runif_01 * 4): both indices are made for all 64 draws at once and
+    // travel as one packed word; the (2^-28) draws whose index depends on their low word mark the whole buffer "exact".
+    uint32_t ds0, ds1, ds2, ds3;
+    {
+        const jk_u128 st = jk_mk128(P.jump[4 * lid + 1], P.jump[4 * lid]) * jk_mk128(R.s_hi, R.s_lo) + jk_mk128(P.jump[4 * lid + 3], P.jump[4 * lid + 2]) * I;
+        ds0 = (uint32_t)st; ds1 = (uint32_t)(st >> 32); ds2 = (uint32_t)(st >> 64); ds3 = (uint32_t)(st >> 96);
+    }
+    uint64_t dc_lo, dc_hi;
+    { const jk_u128 C64 = PB_G64 * I; dc_lo = (uint64_t)C64; dc_hi = (uint64_t)(C64 >> 64); asm volatile("" : "+v"(dc_lo), "+v"(dc_hi)); }
+    uint32_t xb_lo = 0, xb_hi = 0, pk = 0;        // lane j: draw number j of the current buffer: raw words, {index of 3, index of 4 << 8}
+    bool xb_exact = false;                        // some draw of the buffer needs runif_index32
+    auto make_buffer = [&]() {
+        const uint64_t xv = pb_pcg_out(ds0, ds1, ds2, ds3);
         xb_lo = (uint32_t)xv; xb_hi = (uint32_t)(xv >> 32);
-        S = jk_mk128(((uint64_t)pb_rl32(s3, 63) << 32) | pb_rl32(s2, 63), ((uint64_t)pb_rl32(s1, 63) << 32) | pb_rl32(s0, 63));
+        const uint32_t p3 = xb_hi * 3u;
+        pk = __umulhi(xb_hi, 3u) | ((xb_hi >> 30) << 8);
+        xb_exact = __builtin_amdgcn_ballot_w64(p3 >= 0xfffffff0u || (xb_hi << 2) >= 0xfffffff0u) != 0;
     };
+    make_buffer();
+    uint32_t used = 0;                            // draws of the buffer already handed out
     const uint64_t coff = P.g.chrom_off[SEG ? R.ci % P.n_chroms : R.ci];
     const uint8_t* const gseq = P.g.seq;
     // forward: position p of the window is the byte at A + p; reverse: the complement of the one at A - p
     const uint64_t A = coff + (reverse ? R.read_start + space - 1u : R.read_start);
     const uint32_t rcm = reverse ? 2u : 0u;
     const uint32_t bsh = 8u * (reverse ? 3u - (lid & 3u) : (lid & 3u));      // where this lane's base sits in the dword dealt to it
+    const uint32_t bad0 = lid & ~3u;                                          // ds_bpermute address of that dword, block 0 of a group
     const pb_cmask_t cmasks = (pb_cmask_t)(uintptr_t)(P.masks + R.mask_idx);
     uint32_t cur = 0;                             // bases written so far
     const uint32_t nblk = (R.n_pos + 63u) >> 6;
@@ -790,93 +801,118 @@ pb_emit_kernel(PbEmitParams P) {
         }
         return w;
     };
+    // One block of 64 positions.  SAFE: the caller knows that the walk visits all 64, that they lie inside the window and
+    // that this is not the read's last block -- true for all but the last few blocks of a read, and it takes the
+    // end-of-read, end-of-window and flush tests (scalar instructions: a SIMD issues one per four clocks, like vector
+    // ones, and this kernel has as many of them) out of the block.
+    auto do_block = [&](uint32_t b, uint32_t q, uint32_t wsrc, auto safe_tag) {
+        constexpr bool SAFE = decltype(safe_tag)::value;
+        const uint32_t mvx = cmasks[b].x, mvy = cmasks[b].y, mvz = cmasks[b].z, mvw = cmasks[b].w;
+        const uint64_t lo = (uint64_t)mvx | ((uint64_t)mvy << 32), hi = (uint64_t)mvz | ((uint64_t)mvw << 32);
+        const uint64_t insm = lo & ~hi, delm = hi & ~lo, keep = ~delm;
+        const uint32_t off = pb_mbcnt(insm, pb_mbcnt(keep, 0u));          // bases the positions below this lane's add
+        // positions the walk visits: a prefix of the block
+        const uint64_t pm = SAFE ? ~0ULL : __builtin_amdgcn_ballot_w64(off < L - cur);
+        const uint64_t kp = keep & pm, ip = insm & pm, sp = lo & hi & pm;
+        const uint64_t evm = lo & pm;                                     // insertions and substitutions among them: one draw each
+        // ---- this block's draws, in position order (src/hts_pacbio.cpp:384-395): consecutive outputs of the stream by rank
+        // substitution: mm_nucleos[nt][(uint64)(runif_01 * 3)]; insertion: jlp::bases[(uint64)(runif_01 * 4)]
+        uint32_t pkv = 0;
+        uint64_t nulm = 0;                                                // draws that index past their string: its NUL
+        if (evm != 0) {
+            const uint32_t d = used + pb_mbcnt(evm, 0u);
+            const uint32_t ne = (uint32_t)__builtin_popcountll(evm);
+            const int baddr = (int)((d << 2) & 0xfcu);                    // (the same for draw d of this buffer and draw d - 64 of the next)
+            bool exact = xb_exact;
+            uint32_t o_lo = 0, o_hi = 0;
+            const bool two = used + ne > 64u;
+            if (!two) pkv = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)pk);
+            else {
+                const uint32_t p1 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)pk);     // (meaningful where d < 64)
+                o_lo = xb_lo; o_hi = xb_hi;
+                pb_pcg_mad64(ds0, ds1, ds2, ds3, dc_lo, dc_hi);
+                make_buffer();
+                const uint32_t p2 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)pk);
+                pkv = d < 64u ? p1 : p2;
+                exact = exact || xb_exact;
+                used -= 64u;
+            }
+            used += ne;
+            if (exact) {
+                asm volatile("" ::: "memory");
+                uint32_t xh, xl;
+                if (!two) { xh = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xb_hi); xl = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xb_lo); }
+                else {
+                    const uint32_t h1 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)o_hi), l1 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)o_lo);
+                    const uint32_t h2 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xb_hi), l2 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xb_lo);
+                    xh = d < 64u ? h1 : h2;
+                    xl = d < 64u ? l1 : l2;
+                }
+                const bool is_sub = __builtin_amdgcn_inverse_ballot_w64(sp);
+                const uint32_t nidx = is_sub ? 3u : 4u;
+                const uint32_t code = runif_index32(((uint64_t)xh << 32) | xl, nidx);
+                nulm = __builtin_amdgcn_ballot_w64(code >= nidx) & evm;
+                pkv = (code & 3u) | ((code & 3u) << 8);
+            }
+        }
+        // ---- source base
+        const uint32_t p = b * 64u + lid;
+        uint32_t craw = 0;
+        if (SEG) {
+            if (__builtin_amdgcn_inverse_ballot_w64(pm) && p < space) {
+                const uint64_t hpos = reverse ? (R.read_start + space - 1u - p) : (R.read_start + p);
+                int64_t m = hap_search(P.h, R.ci, hpos);
+                craw = gseq[hap_resolve(P.h, coff, R.ci, m, hpos).addr];
+            }
+        } else {
+            const uint32_t wq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(bad0 + 64u * q), (int)wsrc);
+            craw = (wq >> bsh) & 0xffu;
+        }
+        const uint64_t outm = (SAFE || b * 64u + 64u <= space) ? 0ULL : __builtin_amdgcn_ballot_w64(p >= space);     // positions past the window
+        const uint64_t oddm = (__builtin_amdgcn_ballot_w64(craw >= 4u) | outm | nulm) & pm;
+        const uint32_t c = craw ^ rcm;                                    // (complemented on the reverse strand, if it is a base)
+        const bool my_sub = __builtin_amdgcn_inverse_ballot_w64(sp);
+        uint32_t ch, ich;
+        if (oddm == 0) {
+            // every visited position is T, C, A or G inside the window (bytes above the lowest of a result are not stored)
+            const uint32_t c3 = pkv & 0xffu;
+            const uint32_t sc = c3 + (c3 >= c ? 1u : 0u);
+            ch = __builtin_amdgcn_perm(0u, 0x47414354u, my_sub ? sc : c);
+            ich = __builtin_amdgcn_perm(0u, 0x47414354u, pkv >> 8);
+        } else {
+            // characters as the reference's `read` buffer holds them (cmp_map on the reverse strand keeps N and zeroes
+            // everything else that is not a base; positions past the window hold what earlier reads left)
+            const bool proc = __builtin_amdgcn_inverse_ballot_w64(pm), is_nul = __builtin_amdgcn_inverse_ballot_w64(nulm);
+            const uint32_t c3 = pkv & 3u, c4 = (pkv >> 8) & 3u;
+            uint32_t bch, nt;
+            if (p >= space) { bch = proc ? P.stale[R.stale_idx + (p - space)] : 0u; nt = pb_nt_of_char(bch); }
+            else if (craw < 4u) { bch = base_char(c); nt = c; }
+            else { bch = reverse ? (craw == 'N' ? (uint32_t)'N' : 0u) : jk_decode_other(craw); nt = 4u; }
+            const uint32_t sub_ch = is_nul ? 0u : (nt < 4u ? base_char(c3 + (c3 >= nt ? 1u : 0u)) : (uint32_t)'N');
+            ch = my_sub ? sub_ch : bch;
+            ich = is_nul ? 0u : base_char(c4);
+        }
+        const uint32_t ri = ((uint32_t)g + off) & (PB_RING - 1u);
+        if (__builtin_amdgcn_inverse_ballot_w64(kp)) ring[ri] = (uint8_t)ch;
+        if (__builtin_amdgcn_inverse_ballot_w64(ip)) ring[(ri + 1u) & (PB_RING - 1u)] = (uint8_t)ich;
+        const uint32_t nb = (uint32_t)__builtin_popcountll(kp) + (uint32_t)__builtin_popcountll(ip);
+        cur += nb; g += nb;
+    };
     uint32_t wsrc = load_group(0);
     for (uint32_t b0 = 0; b0 < nblk && cur < L; b0 += 4u) {
         const uint32_t wnext = (b0 + 4u < nblk) ? load_group((b0 + 4u) * 64u) : 0u;      // (requested a group ahead)
-        for (uint32_t q = 0; q < 4u && b0 + q < nblk && cur < L; q++) {
-            const uint32_t b = b0 + q;
-            const uint32_t mvx = cmasks[b].x, mvy = cmasks[b].y, mvz = cmasks[b].z, mvw = cmasks[b].w;
-            const uint64_t lo = (uint64_t)mvx | ((uint64_t)mvy << 32), hi = (uint64_t)mvz | ((uint64_t)mvw << 32);
-            const uint64_t insm = lo & ~hi, delm = hi & ~lo, keep = ~delm;
-            const uint32_t off = pb_mbcnt(insm, pb_mbcnt(keep, 0u));          // bases the positions below this lane's add
-            const uint32_t need = L - cur;
-            const bool proc = off < need;                                     // positions the walk visits: a prefix of the block
-            const uint64_t pm = __builtin_amdgcn_ballot_w64(proc);
-            const uint64_t evm = lo & pm;                                     // insertions and substitutions among them: one draw each
-            const uint32_t p = b * 64u + lid;
-            const bool my_ev = (evm >> lid) & 1ULL, my_sub = my_ev && ((hi >> lid) & 1ULL);
-            const bool my_ins = my_ev && !my_sub, my_keep = (keep >> lid) & 1ULL;
-            // ---- this block's draws, in position order (src/hts_pacbio.cpp:384-395): consecutive outputs of the stream by rank
-            // substitution: mm_nucleos[nt][(uint64)(runif_01 * 3)]; insertion: jlp::bases[(uint64)(runif_01 * 4)]
-            const uint32_t nidx = my_sub ? 3u : 4u;
-            uint32_t code = 0;
-            bool is_nul = false;
-            if (evm != 0) {
-                const uint32_t d = used + pb_mbcnt(evm, 0u);
-                const uint32_t ne = (uint32_t)__builtin_popcountll(evm);
-                uint32_t xh, xl = 0;
-                const bool two = used + ne > 64u;
-                uint32_t o_lo = xb_lo, o_hi = xb_hi;                          // (the old buffer, should the exact path want its low words)
-                if (!two) xh = (uint32_t)__shfl((int)xb_hi, (int)(d & 63u), 64);
-                else {
-                    const uint32_t x1 = (uint32_t)__shfl((int)xb_hi, (int)(d & 63u), 64);     // (meaningful where d < 64)
-                    refill();
-                    const uint32_t x2 = (uint32_t)__shfl((int)xb_hi, (int)((d - 64u) & 63u), 64);
-                    xh = d < 64u ? x1 : x2;
-                    used -= 64u;
-                }
-                used += ne;
-                // (uint64)(runif_01 * n) = hi32(xh * n + carry of the low word) unless the low half of xh * n is within n + 1
-                // of wrapping (2^-30 per draw): then the low word of the draw is fetched and runif_index32 decides
-                code = __umulhi(xh, nidx);
-                if (__builtin_amdgcn_ballot_w64(my_ev && xh * nidx >= 0xfffffff0u) != 0) {
-                    asm volatile("" ::: "memory");
-                    if (!two) xl = (uint32_t)__shfl((int)xb_lo, (int)(d & 63u), 64);
-                    else {
-                        const uint32_t l1 = (uint32_t)__shfl((int)o_lo, (int)(d & 63u), 64), l2 = (uint32_t)__shfl((int)xb_lo, (int)((d - 64u) & 63u), 64);
-                        xl = d < 64u ? l1 : l2;
-                    }
-                    code = runif_index32(((uint64_t)xh << 32) | xl, nidx);
-                    is_nul = my_ev && code >= nidx;                                // index past the string: its NUL
-                }
-                (void)o_hi;
+        // a group of four blocks that cannot reach the end of the read (a block adds at most 128 bases) or of the window
+        if (cur + 512u <= L && (b0 + 4u) * 64u <= space && b0 + 4u < nblk) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) do_block(b0 + q, q, wsrc, std::true_type());
+            flush_full();                      // (at most 1023 + 512 bytes are pending here: the ring holds 2048)
+        } else {
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) {
+                if (b0 + q >= nblk || cur >= L) break;
+                do_block(b0 + q, q, wsrc, std::false_type());
+                flush_full();
             }
-            // ---- source base
-            const bool inwin = p < space;
-            uint32_t craw = 0;
-            if (SEG) {
-                if (proc && inwin) {
-                    const uint64_t hpos = reverse ? (R.read_start + space - 1u - p) : (R.read_start + p);
-                    int64_t m = hap_search(P.h, R.ci, hpos);
-                    craw = gseq[hap_resolve(P.h, coff, R.ci, m, hpos).addr];
-                }
-            } else {
-                const uint32_t wq = (uint32_t)__shfl((int)wsrc, (int)(16u * q + (lid >> 2)), 64);
-                craw = (wq >> bsh) & 0xffu;
-            }
-            const uint32_t c = craw ^ rcm;                                    // (complemented on the reverse strand, if it is a base)
-            uint32_t ch, ich;
-            if (__builtin_amdgcn_ballot_w64(proc && (craw >= 4u || !inwin || is_nul)) == 0) {
-                // every visited position is T, C, A or G inside the window (bytes above the lowest of a result are not stored)
-                const uint32_t sc = code + (code >= c ? 1u : 0u);
-                ch = __builtin_amdgcn_perm(0u, 0x47414354u, my_sub ? sc : c);
-                ich = __builtin_amdgcn_perm(0u, 0x47414354u, code);
-            } else {
-                // characters as the reference's `read` buffer holds them (cmp_map on the reverse strand keeps N and zeroes
-                // everything else that is not a base; positions past the window hold what earlier reads left)
-                uint32_t bch, nt;
-                if (!inwin) { bch = proc ? P.stale[R.stale_idx + (p - space)] : 0u; nt = pb_nt_of_char(bch); }
-                else if (craw < 4u) { bch = base_char(c); nt = c; }
-                else { bch = reverse ? (craw == 'N' ? (uint32_t)'N' : 0u) : jk_decode_other(craw); nt = 4u; }
-                const uint32_t sub_ch = is_nul ? 0u : (nt < 4u ? base_char(code + (code >= nt ? 1u : 0u)) : (uint32_t)'N');
-                ch = my_sub ? sub_ch : bch;
-                ich = is_nul ? 0u : base_char(code & 3u);
-            }
-            if (proc && my_keep) put(off, ch);
-            if (proc && my_ins) put(off + 1u, ich);
-            const uint32_t nb = (uint32_t)__builtin_popcountll(keep & pm) + (uint32_t)__builtin_popcountll(insm & pm);
-            cur += nb; g += nb;
-            flush_full();
         }
         wsrc = wnext;
     }
