@@ -112,6 +112,8 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
             Q.stale = s.d_pb_stale[set].as<uint8_t>();
             Q.stale_ctr = s.d_pb_ctr[set].as<uint32_t>() + 2;
             if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));      // the set is free once its emit kernel is done
+            static const bool pb_serial = std::getenv("JK_PB_SERIAL") && std::atoi(std::getenv("JK_PB_SERIAL")) != 0;   // experiment: no overlap of plan and emit
+            if (pb_serial && b >= 1) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 1], 0));
             JK_HIP(hipEventRecord(s.events[ev++], s.stream));
             JK_HIP(hipMemsetAsync(s.d_pb_recs[set].p, 0, std::max<uint64_t>(B.n_reads, 1) * sizeof(PbRead), s.stream));
             JK_HIP(hipMemsetAsync(s.d_pb_ctr[set].p, 0, 16, s.stream));

@@ -147,6 +147,25 @@ __device__ __forceinline__ uint32_t pb_mbcnt(uint64_t m, uint32_t acc) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, acc));
 }
 
+// One block of event masks to memory, from the scalar registers where the ballots leave them: gfx950 has the scalar
+// stores of the gfx9 family; they go through the scalar data cache, which is written back (s_dcache_wb) before anybody
+// reads them.  A vector store needs the four words moved to vector registers and the other lanes masked off first:
+// 41.5 against 39.4 M reads/s on BASELINE configs[4] (-DJK_PB_NO_SSTORE for that form).
+__device__ __forceinline__ void pb_store_masks(uint4* p, uint64_t plo, uint64_t phi, uint32_t lid) {
+#ifndef JK_PB_NO_SSTORE
+    typedef uint32_t pb_u4v __attribute__((ext_vector_type(4)));
+    const pb_u4v v = {(uint32_t)plo, (uint32_t)(plo >> 32), (uint32_t)phi, (uint32_t)(phi >> 32)};
+    asm volatile("s_store_dwordx4 %0, %1, 0x0" :: "s"(v), "s"(p) : "memory");
+    (void)lid;
+#else
+    if (lid == 0) *p = make_uint4((uint32_t)plo, (uint32_t)(plo >> 32), (uint32_t)phi, (uint32_t)(phi >> 32));
+#endif
+}
+__device__ __forceinline__ void pb_masks_written() {
+#ifndef JK_PB_NO_SSTORE
+    asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
 // XSL-RR output of a state given as limbs (the second half of jk_pcg_next)
 __device__ __forceinline__ uint64_t pb_pcg_out(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3) {
     const uint32_t x_lo = s0 ^ s2, x_hi = s1 ^ s3, rot = s3 >> 26;
@@ -436,7 +455,7 @@ pb_plan_kernel(PacbioKernelParams P) {
                                 const uint64_t ins = ~qn & qi, nd_ = ~qn & ~qi, del = nd_ & qd, sub = nd_ & ~qd;
                                 si += (uint32_t)__builtin_popcountll(ins); sd += (uint32_t)__builtin_popcountll(del); ss += (uint32_t)__builtin_popcountll(sub);
                                 const uint64_t plo_ = ins | sub, phi_ = nd_;          // (deletion or substitution: neither none nor insertion)
-                                if (lid == 0) mp[q] = make_uint4((uint32_t)plo_, (uint32_t)(plo_ >> 32), (uint32_t)phi_, (uint32_t)(phi_ >> 32));
+                                pb_store_masks(mp + q, plo_, phi_, lid);
                                 pb_pcg_mad64(s0, s1, s2, s3, c_lo, c_hi);
                             }
                             cur += 64u * nsafe + si - sd; extra += si - sd;
@@ -514,7 +533,7 @@ pb_plan_kernel(PacbioKernelParams P) {
                             k++; upos++;
                         }
                     }
-                    if (lid == 0) P.masks[mk0 + ((upos - k) >> 6)] = make_uint4((uint32_t)plo, (uint32_t)(plo >> 32), (uint32_t)phi, (uint32_t)(phi >> 32));
+                    pb_store_masks(P.masks + mk0 + ((upos - k) >> 6), plo, phi, lid);
                     if (cur >= L32 || upos >= max_pos) {                 // k >= 1 here: the stream stands behind its k-th draw of this block
                         e0 = pb_rl32(s0, k - 1u); e1 = pb_rl32(s1, k - 1u); e2 = pb_rl32(s2, k - 1u); e3 = pb_rl32(s3, k - 1u);
                         break;
@@ -529,7 +548,8 @@ pb_plan_kernel(PacbioKernelParams P) {
                 r_pos = upos; r_nins = n_ins; r_ndel = n_del; r_nsub = n_sub; r_fl = fl; r_mk = mk0;
             }
         }
-        // (the mask blocks were stored by lane 0; a lane may read its own below)
+        // (the mask blocks were stored by lane 0 / from scalar registers; a lane may read its own below)
+        pb_masks_written();
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
         // ---------------- per lane again: start, strand, the record ----------------
@@ -725,14 +745,19 @@ pb_emit_kernel(PbEmitParams P) {
     auto flush_segment = [&](uint64_t upto) {
         __syncthreads();
         const uint64_t seg = flushed & ~1023ULL;
-        const uint64_t pa = seg + 16u * lid;                 // this lane's 16-byte piece
-        const uint64_t plo = pa > flushed ? pa : flushed, phi = pa + 16u < upto ? pa + 16u : upto;
-        if (plo < phi) {
-            if (phi - plo == 16u) {
-                const uint4 v = *reinterpret_cast<const uint4*>(ring + ((uint32_t)pa & (PB_RING - 1u)));
-                *reinterpret_cast<uint4*>((uintptr_t)pa) = v;
-            } else {
-                for (uint64_t a = plo; a < phi; a++) *reinterpret_cast<uint8_t*>((uintptr_t)a) = ring[(uint32_t)a & (PB_RING - 1u)];
+        if (flushed == seg && upto == seg + 1024u) {         // a whole segment (all but the first and last of a read)
+            const uint4 v = *reinterpret_cast<const uint4*>(ring + ((uint32_t)seg & (PB_RING - 1u)) + 16u * lid);
+            reinterpret_cast<uint4*>((uintptr_t)seg)[lid] = v;
+        } else {
+            const uint64_t pa = seg + 16u * lid;                 // this lane's 16-byte piece
+            const uint64_t plo = pa > flushed ? pa : flushed, phi = pa + 16u < upto ? pa + 16u : upto;
+            if (plo < phi) {
+                if (phi - plo == 16u) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(ring + ((uint32_t)pa & (PB_RING - 1u)));
+                    *reinterpret_cast<uint4*>((uintptr_t)pa) = v;
+                } else {
+                    for (uint64_t a = plo; a < phi; a++) *reinterpret_cast<uint8_t*>((uintptr_t)a) = ring[(uint32_t)a & (PB_RING - 1u)];
+                }
             }
         }
         flushed = upto;
@@ -747,9 +772,17 @@ pb_emit_kernel(PbEmitParams P) {
         flush_full();
     }
     if (lid < nd) {
-        uint64_t p10 = 1;
-        for (uint32_t j = lid + 1u; j < nd; j++) p10 *= 10u;
-        put(lid, '0' + (uint32_t)((R.read_start / p10) % 10u));
+        uint32_t dg;
+        if (R.read_start <= 0xffffffffULL) {      // (64-bit division is a subroutine of hundreds of instructions)
+            uint32_t p10 = 1;
+            for (uint32_t j = lid + 1u; j < nd; j++) p10 *= 10u;
+            dg = ((uint32_t)R.read_start / p10) % 10u;
+        } else {
+            uint64_t p10 = 1;
+            for (uint32_t j = lid + 1u; j < nd; j++) p10 *= 10u;
+            dg = (uint32_t)((R.read_start / p10) % 10u);
+        }
+        put(lid, '0' + dg);
     }
     if (lid == 61u) put(nd, '-');
     if (lid == 62u) put(nd + 1u, reverse ? 'R' : 'F');
