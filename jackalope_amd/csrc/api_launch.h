@@ -112,12 +112,20 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
             Q.stale = s.d_pb_stale[set].as<uint8_t>();
             Q.stale_ctr = s.d_pb_ctr[set].as<uint32_t>() + 2;
             if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));      // the set is free once its emit kernel is done
-            static const bool pb_serial = std::getenv("JK_PB_SERIAL") && std::atoi(std::getenv("JK_PB_SERIAL")) != 0;   // experiment: no overlap of plan and emit
+            // Both kernels are bound by instruction issue, so running the plan kernel of launch b beside the emit kernel of
+            // launch b - 1 wins little (147 against 153 ms per step on BASELINE configs[4] at 2^21 lanes) and, when the
+            // plan kernel's waves carry fewer than 64 lanes, loses (164 against 155 ms at 2^20 lanes, 172 against 158 at
+            // 2^19): then the kernels take turns.  JK_PB_SERIAL=0/1 to choose.
+            bool pb_serial = s.pb_wave_lanes[b] < 64;
+            if (const char* e = std::getenv("JK_PB_SERIAL")) pb_serial = std::atoi(e) != 0;
             if (pb_serial && b >= 1) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 1], 0));
             JK_HIP(hipEventRecord(s.events[ev++], s.stream));
             JK_HIP(hipMemsetAsync(s.d_pb_recs[set].p, 0, std::max<uint64_t>(B.n_reads, 1) * sizeof(PbRead), s.stream));
             JK_HIP(hipMemsetAsync(s.d_pb_ctr[set].p, 0, 16, s.stream));
-            const uint32_t pgrid = (B.n_lanes + PB_PLAN_BLOCK - 1) / PB_PLAN_BLOCK;
+            const uint32_t wl = s.pb_wave_lanes[b];
+            Q.wave_lanes = wl;
+            const uint32_t n_waves = (B.n_lanes + wl - 1) / wl;
+            const uint32_t pgrid = (n_waves * 64u + PB_PLAN_BLOCK - 1) / PB_PLAN_BLOCK;
             if (s.hap) hipLaunchKernelGGL((pb_plan_kernel<true>), dim3(pgrid), dim3(PB_PLAN_BLOCK), 0, s.stream, Q);
             else hipLaunchKernelGGL((pb_plan_kernel<false>), dim3(pgrid), dim3(PB_PLAN_BLOCK), 0, s.stream, Q);
             JK_HIP(hipGetLastError());

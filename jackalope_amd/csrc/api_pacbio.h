@@ -133,9 +133,33 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     PhaseTimer pt("pacbio: plan, alloc, upload");
     const std::vector<uint64_t>& lane_reads = lp.lane_reads;
     const uint64_t rec_mean = max_hdr + n_digits(max_chrom) + 3 + 2 * (uint64_t)std::ceil(M.len_mean) + 8;
-    const uint64_t batch_bytes = max_batch_bytes ? max_batch_bytes : (16ULL << 30);
+    // A launch = whole lanes with all their reads.  The plan kernel is a dependent chain per wave and wants four waves
+    // on every SIMD (`slots`), no more (a fifth runs after the others: the launch then takes twice as long) and not many
+    // fewer; its waves carry wl = 1..64 lanes each.  So a launch takes slots x wl lanes, with wl the largest power of two
+    // that keeps its expected FASTQ within the batch size (16 GB unless max_batch_bytes says otherwise) -- and when the
+    // run has few lanes with many reads each, a launch still takes `slots` of them if memory allows (up to 96 GB of
+    // image per launch: the scratch is an eighth of that), since a lane's reads cannot be spread over launches.
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s.device);
+    const uint64_t slots = (uint64_t)n_cu * 16;
+    uint64_t batch_bytes = max_batch_bytes ? max_batch_bytes : (16ULL << 30);
     uint64_t max_batch_lanes = 1ULL << 18;
+    uint32_t wave_lanes = 64;
+    {
+        uint64_t reads_shard = 0;
+        for (uint64_t v : lane_reads) reads_shard += v;
+        const double per_lane = s.n_shard ? (double)reads_shard / (double)s.n_shard * (double)rec_mean : 1.0;   // expected bytes of a lane
+        if (!max_batch_bytes) {
+            const double want = per_lane * (double)std::min<uint64_t>(s.n_shard, slots);
+            const double cap = s.streaming ? 40e9 : 96e9;
+            if (want > (double)batch_bytes) batch_bytes = (uint64_t)std::min(want, cap);
+        }
+        const uint64_t by_bytes = std::max<uint64_t>(64, (uint64_t)((double)batch_bytes / std::max(per_lane, 1.0)));
+        while (wave_lanes > 1 && slots * wave_lanes > by_bytes) wave_lanes >>= 1;
+        max_batch_lanes = std::max<uint64_t>(64, std::min<uint64_t>(slots * wave_lanes, by_bytes) / 64 * 64);
+    }
     if (const char* e = std::getenv("JK_BATCH_LANES")) { const long long v = std::atoll(e); if (v >= 64) max_batch_lanes = (uint64_t)v / 64 * 64; }
+    if (const char* e = std::getenv("JK_PB_WAVE_LANES")) { const int v = std::atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) wave_lanes = (uint32_t)v; }
     s.batches.clear(); s.batch_pool_off_index.clear();
     std::vector<uint64_t> rec_off(std::max<uint64_t>(s.n_shard, 1), 0);
     uint64_t max_reads = 0, total_reads = 0;
@@ -161,7 +185,18 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     s.img_cap = image_for(max_reads);
     // event masks: 16 bytes per 64 positions of a read's walk (about its length), taken from the arena in chunks per wave
     const uint64_t blocks_per_read = (uint64_t)(M.len_mean * 1.15) / 64 + 2;
-    s.pb_mask_cap = (uint64_t)((double)(max_reads * blocks_per_read) * s.pool_scale) + ((uint64_t)max_lanes / 64 + 1) * PB_MASK_CHUNK;
+    // lanes per wave of each launch's plan kernel (a launch with fewer lanes than planned -- the last one -- spreads them thinner)
+    uint64_t max_waves = 1;
+    s.pb_wave_lanes.clear();
+    for (const Batch& b : s.batches) {
+        uint32_t wl = wave_lanes;
+        while (wl > 1 && (uint64_t)b.n_lanes / wl < slots && !std::getenv("JK_PB_WAVE_LANES")) wl >>= 1;
+        while (wl < 64 && ((uint64_t)b.n_lanes + wl - 1) / wl > slots) wl <<= 1;
+        s.pb_wave_lanes.push_back(wl);
+        max_waves = std::max<uint64_t>(max_waves, (b.n_lanes + wl - 1) / wl);
+    }
+    // (every wave may leave most of its last chunk unused)
+    s.pb_mask_cap = (uint64_t)((double)(max_reads * blocks_per_read) * s.pool_scale) + (max_waves + 1) * PB_MASK_CHUNK;
     s.pb_stale_cap = (uint32_t)std::min<double>((double)(1u << 30), (double)(1u << 20) * s.pool_scale);
     const uint64_t sets = s.batches.size() > 1 ? 2 : 1;
     {

@@ -59,7 +59,7 @@ struct PbRead {
     uint32_t L, space, n_pos, split;   // read length, read_chrom_space, positions the walk visits, split_pos (clamped to L)
     uint32_t lane;                // lane of the launch (seed words -> stream increment; lane offset in the image)
     uint32_t ci;                  // chromosome / (haplotype, chromosome) cell
-    uint32_t flags;               // bit 0: the read is made, bit 1: reverse strand; bits 8-15 / 16-23: left / right quality character
+    uint32_t flags;               // bit 0: the read is made, bit 1: reverse strand, bit 2: L + 1 bases; bits 8-15 / 16-23: left / right quality character
     uint32_t stale_idx;           // first of its n_pos - space bytes in the stale buffer (positions past the window, see below)
 };
 // decimal digits of v (std::to_string(read_start) in the id line)
@@ -79,6 +79,7 @@ struct PacbioKernelParams {
     HapDev h;
     uint32_t hap_seg;             // haplotypes read through the mutation tables (else g.chrom_off is indexed by cell: materialised)
     uint32_t n_lanes;
+    uint32_t wave_lanes;          // lanes per wave (a power of two up to 64)
     const uint32_t* seeds;
     const uint64_t* lane_reads;
     const uint32_t* chrom_reads;  // [chrom or cell][lane]
@@ -161,9 +162,13 @@ __device__ __forceinline__ void pb_store_masks(uint4* p, uint64_t plo, uint64_t 
     if (lid == 0) *p = make_uint4((uint32_t)plo, (uint32_t)(plo >> 32), (uint32_t)phi, (uint32_t)(phi >> 32));
 #endif
 }
+// ... and before a lane reads mask blocks back with vector loads: the scalar stores went past this CU's vector L1, which
+// may still hold an older copy of a 128-byte line they wrote into (found by the randomised sweep: a lane re-walking its
+// masks saw the line as an earlier read had left it), so the L1 is invalidated (agent-scope acquire: buffer_inv sc1).
 __device__ __forceinline__ void pb_masks_written() {
 #ifndef JK_PB_NO_SSTORE
     asm volatile("s_dcache_wb\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
 }
 // XSL-RR output of a state given as limbs (the second half of jk_pcg_next)
@@ -239,9 +244,12 @@ __device__ __forceinline__ uint32_t pb_nt_of_char(uint32_t ch) { return ch == 'T
 template <bool HAP>
 __global__ void __launch_bounds__(PB_PLAN_BLOCK) JK_PB_PLAN_ATTR
 pb_plan_kernel(PacbioKernelParams P) {
-    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    // A wave carries P.wave_lanes (1..64) lanes of the launch, in its first threads: the per-lane phases are a small part of
+    // the work and pass 1 uses all 64 threads whatever the number of streams, so a launch of few lanes (few reference
+    // threads with many reads each) still fills the device with waves.
     const uint32_t lid = pb_lane_id();
-    const bool valid = lane < P.n_lanes;
+    const uint32_t lane = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * P.wave_lanes + lid;
+    const bool valid = lid < P.wave_lanes && lane < P.n_lanes;
     const uint32_t lane_c = valid ? lane : 0;
 
     LaneRng rng;
@@ -416,7 +424,9 @@ pb_plan_kernel(PacbioKernelParams P) {
             const uint32_t L32 = pb_rl32((uint32_t)L, s), sp32 = pb_rl32(split32, s);
             uint32_t extra = pb_rl32(extra0, s);
             const uint32_t max_pos = 2u * L32 + 64u;                // the walk may take this many positions (L <= 2^30)
-            const uint32_t nb_max = (max_pos + 63u) >> 6;
+            // (a read's blocks start on a 64-byte line of their own: the scalar data cache writes lines back, and a line that a
+            // lane patches below -- a duplicate losing deletions -- must not be written again by a later read's scalar stores)
+            const uint32_t nb_max = (((max_pos + 63u) >> 6) + 3u) & ~3u;
             uint32_t fl = 0;
             if (mk_ptr + nb_max > mk_end) {                         // the wave's piece of the arena is used up: take another
                 const uint64_t want = nb_max > PB_MASK_CHUNK ? nb_max : PB_MASK_CHUNK;
@@ -541,7 +551,7 @@ pb_plan_kernel(PacbioKernelParams P) {
                     pb_pcg_mad64(s0, s1, s2, s3, c_lo, c_hi);
                 }
                 if (cur < L32) fl |= 2u;
-                mk_ptr = mk0 + ((upos + 63u) >> 6);
+                mk_ptr = mk0 + ((((upos + 63u) >> 6) + 3u) & ~3ULL);
             }
             if (lid == s) {                                         // back to the lane that owns the stream
                 rng.e.s0 = e0; rng.e.s1 = e1; rng.e.s2 = e2; rng.e.s3 = e3;
@@ -589,7 +599,7 @@ pb_plan_kernel(PacbioKernelParams P) {
             if (give_up) break;
             // ---- append_pool (src/hts_pacbio.cpp:350-414): strand, then the walk's draws are jumped over
             const bool reverse = jk_runif_lt_half(rng());
-            uint32_t n_walk = pos, n_draws = r_nins + r_nsub;
+            uint32_t n_walk = pos, n_draws = r_nins + r_nsub, over = 0;
             if (differs) {
                 // how far the walk gets, and how many insertions / substitutions it meets: position k is visited while
                 // k + #ins(< k) - #del(< k) < L
@@ -616,19 +626,22 @@ pb_plan_kernel(PacbioKernelParams P) {
                     const uint32_t kcut = a + 1u;      // positions < kcut of this block are visited
                     const uint64_t procm = kcut >= 64u ? ~0ULL : ((1ULL << kcut) - 1ULL);
                     n_draws += (uint32_t)__builtin_popcountll(lo & procm);
+                    // an insertion that pass 1 recorded may be the walk's last position: the read then has L + 1 bases
+                    // (src/hts_pacbio.cpp:384-388 adds two at once; the quality line keeps L characters)
+                    over = (uint32_t)((uint64_t)kcut + (uint64_t)__builtin_popcountll(insm & procm) - (uint64_t)__builtin_popcountll(delm & procm) - need);
                     p += kcut; cur2 = L;
                 }
                 if (cur2 < L || p > pos) { err |= JK_KERR_PB_SPACE; break; }      // (cannot happen: the walk never needs more positions than pass 1)
                 n_walk = p;
             }
             const uint32_t hdr_len = P.g.hdr_off[ci + 1] - P.g.hdr_off[ci];
-            const uint64_t out_len = (uint64_t)hdr_len + jk_dec_digits(read_start) + 3u + L + 3u + L + 1u;
+            const uint64_t out_len = (uint64_t)hdr_len + jk_dec_digits(read_start) + 3u + L + over + 3u + L + 1u;
             PbRead R;
             R.s_lo = ((uint64_t)rng.e.s1 << 32) | rng.e.s0; R.s_hi = ((uint64_t)rng.e.s3 << 32) | rng.e.s2;
             R.out_off = out_pos; R.mask_idx = r_mk; R.read_start = read_start;
             R.L = (uint32_t)L; R.space = (uint32_t)space; R.n_pos = n_walk; R.split = split32 < (uint32_t)L ? split32 : (uint32_t)L;
             R.lane = lane; R.ci = ci;
-            R.flags = 1u | (reverse ? 2u : 0u) | (quals << 0);
+            R.flags = 1u | (reverse ? 2u : 0u) | (over ? 4u : 0u) | (quals << 0);
             R.stale_idx = 0;
             if ((uint64_t)n_walk > space) {
                 // positions past this read's window: the characters earlier reads left in the buffer
@@ -733,7 +746,7 @@ pb_emit_kernel(PbEmitParams P) {
     const bool reverse = (R.flags & 2u) != 0;
     const uint32_t h0 = P.g.hdr_off[R.ci], hlen = P.g.hdr_off[R.ci + 1] - h0;
     const uint32_t nd = jk_dec_digits(R.read_start);
-    const uint64_t out_len = (uint64_t)hlen + nd + 3u + L + 3u + L + 1u;
+    const uint64_t out_len = (uint64_t)hlen + nd + 3u + L + ((R.flags >> 2) & 1u) + 3u + L + 1u;
     const uint64_t at = P.out_base[0] + P.lane_off[R.lane] + R.out_off;
     // the image is allocated for the expected size: never write past it
     if (at + out_len > P.out_cap) { if (lid == 0) atomicOr(P.err, JK_KERR_IMAGE_FULL); return; }

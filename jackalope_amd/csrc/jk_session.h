@@ -46,6 +46,7 @@ struct jk_session {
     // event-mask arena, stale characters, {mask counter, stale counter}
     DevBuf d_pb_recs[2], d_pb_masks[2], d_pb_stale[2], d_pb_ctr[2];
     uint64_t pb_mask_cap = 0; uint32_t pb_stale_cap = 0;
+    std::vector<uint32_t> pb_wave_lanes;          // per launch: lanes per wave of the plan kernel
     uint32_t ev_words = 0;
     uint64_t nuc_base = 0;     // offset of the haplotypes' nucleotide blob inside d_seq
     double pool_scale = 1.25;  // PacBio: scratch capacity (event masks, stale characters) relative to the expected need (grown on overflow)

@@ -104,15 +104,29 @@ def illumina_case(ja, O, rng, case):
     return "ok", desc
 
 
-def pacbio_case(ja, O, rng, case):
+def pacbio_case(ja, O, rng, case, round3=True):
+    """round3=False: the case generator of rounds 1-2 (the regression cases of tests/test_gpu_fuzz.py name its draws)."""
     from test_gpu_pacbio import hip
-    sizes = [int(rng.integers(20_000, 300_000)) for _ in range(int(rng.choice([1, 2, 4])))]
+    if round3:
+        # chromosomes from a few hundred bases (reads as long as their chromosome, no spare bases for deletions, windows that
+        # end inside the 1000-character buffer the reference's thread starts with) to a few hundred kb
+        small = rng.random() < 0.35
+        sizes = [int(rng.integers(300, 6000)) if small else int(rng.integers(20_000, 300_000)) for _ in range(int(rng.choice([1, 2, 4])))]
+    else:
+        small = False
+        sizes = [int(rng.integers(20_000, 300_000)) for _ in range(int(rng.choice([1, 2, 4])))]
     g = ja.synthetic_genome(sizes, seed=int(rng.integers(0, 10 ** 6)))
     T = int(rng.choice([1, 3, 64, 130]))
     n = int(rng.integers(1, 6)) * T + int(rng.integers(0, 3))
+    if round3 and rng.random() < 0.2:
+        n = int(rng.integers(20, 120)) * T                    # many reads per lane: the plan kernel's waves carry few lanes
     pb = {}
     if rng.random() < 0.6:
-        pb["custom_read_lengths"] = sorted(int(x) for x in rng.integers(100, min(sizes) // 3, size=int(rng.integers(1, 5))))
+        if round3:
+            pb["custom_read_lengths"] = sorted(int(x) for x in rng.integers(100, max(min(sizes) // 3, 102) if not small or rng.random() < 0.5 else 2 * max(sizes),
+                                                                            size=int(rng.integers(1, 5))))
+        else:
+            pb["custom_read_lengths"] = sorted(int(x) for x in rng.integers(100, min(sizes) // 3, size=int(rng.integers(1, 5))))
     if rng.random() < 0.3:
         pb["prob_dup"] = float(rng.choice([0.1, 0.5]))
     if rng.random() < 0.3:
