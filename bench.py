@@ -304,8 +304,12 @@ def timed_steps(a, sess, use_dist):
     sync()
     t0 = time.perf_counter()
     gen_ms = all_ms = 0.0
+    global STEP_MS
+    STEP_MS = []
     for _ in range(a.steps):
+        t1 = time.perf_counter()
         sess.generate()                      # blocks until the step's stream work is done
+        STEP_MS.append((time.perf_counter() - t1) * 1e3)
         tm = sess.timing_ms()                # HIP events on the stream the kernels run on
         gen_ms += tm["generate_kernel"]
         all_ms += tm["total"]
@@ -315,6 +319,19 @@ def timed_steps(a, sess, use_dist):
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     return float(tmax.item()), gen_ms, all_ms
+
+
+STEP_MS = []
+
+
+def step_spread():
+    """min / median / max wall time of this rank's timed steps (each generate() returns when its step's device work is
+    done): box-to-box and step-to-step spread belongs in the record next to the mean the contract asks for."""
+    v = sorted(STEP_MS)
+    if not v:
+        return None
+    return {"min": round(v[0], 3), "median": round(v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]), 3),
+            "max": round(v[-1], 3)}
 
 
 def measured_copy_gbs():
@@ -384,7 +401,7 @@ def pacbio_main(a):
                "config": {"workload": "configs[4]: %g Mbp synthetic ref, PacBio defaults, custom read lengths uniform "
                                       "5-15 kb (mean 10 kb), 20x per GPU" % mbp, "reads_per_gpu": n_reads // world, "lanes_per_gpu": lanes // world,
                           "parallelism": "lanes sharded over %d GPU(s), no data-path collective" % world},
-               "gbases_per_sec": round(total_bytes[0] / 2 * a.steps / elapsed / 1e9, 2),
+               "gbases_per_sec": round(total_bytes[0] / 2 * a.steps / elapsed / 1e9, 2), "step_ms": step_spread(),
                "roofline": {"bound": "hbm", "achieved": round(alg / kern_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(alg / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "pb_plan_kernel + pb_emit_kernel",
                             "launches_per_step": n_launch, "kernel_ms": round(kern_s * 1e3, 3), "plan_kernel_ms": round(gen_ms / a.steps / n_launch, 3),
@@ -446,7 +463,7 @@ def hap_main(a):
             "metric": "M paired reads/sec (PE150, 3 Gbp x 8 haplotypes)", "value": round(total_reads / 2 * a.steps / elapsed / 1e6, 3),
             "unit": "M paired reads/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
+            "dtype": "u64", "data": "synthetic", "step_ms": step_spread(),
             "config": {"workload": "configs[3] share per GPU: %.3g Gbp reference, 8 haplotypes (%d mutations), 30x PE150 / 8"
                                    % (n_chroms * chrom_len / 1e9, int(hs.n_mut.sum())), "pairs_per_gpu": pairs_per_gpu,
                        "lanes_per_gpu": lanes_per_gpu, "open_seconds": round(open_s, 2),
@@ -540,7 +557,7 @@ def main():
                                  "traffic = (2*FETCH_SIZE + WRITE_SIZE) of the committed rocprofv3 --pmc passes "
                                  "(profiles/), null when they were taken at another launch size"
                                  % (1206.0 * pairs_rank / n_launch / kern_s)},
-            "device_ms_per_step": round(all_ms / a.steps, 3),
+            "device_ms_per_step": round(all_ms / a.steps, 3), "step_ms": step_spread(),
         }
         # Since round 2 a launch takes 7/8 of the CUs and the compaction of the launch before runs on the rest, beside
         # it: per launch the generator kernel is slower than on the whole chip (roofline.kernel_ms), the step is faster.

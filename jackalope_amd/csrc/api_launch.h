@@ -21,7 +21,9 @@ struct StreamCtx {
         for (uint32_t e = 0; e < s.n_ends; e++) files.emplace_back(new FastqFile(s, e, suffix));
         th = std::thread([this] { run(); });
     }
-    ~StreamCtx() { close(); }
+    // (the files close after this body: no writer thread may still hold a task with their descriptors -- an error path
+    //  gets here without finish(), and a re-plan reopens the same names right afterwards)
+    ~StreamCtx() { close(); pipe.quiesce(); }
     void push(int b) { { std::lock_guard<std::mutex> l(m); q.push_back(b); } cv.notify_all(); }
     void close() {
         { std::lock_guard<std::mutex> l(m); closed = true; }
@@ -282,6 +284,7 @@ static void launch_generate(jk_session& s) {
 // open-ended (another part is appended behind it)
 static void launch_stream(jk_session& s, const std::string& suffix = "", bool with_eof = true, uint64_t* file_bytes = nullptr) {
     if (!s.streaming) throw Error(JK_ERR_ARG, "jk_session_run needs a session opened with stream_output");
+    JK_HIP(hipSetDevice(s.device));          // (the pipe's stream and events, made on first use, belong to this device)
     StreamCtx sc(s, suffix);
     launch_batches(s, &sc);
     for (uint32_t e = 0; e < s.n_ends; e++) {

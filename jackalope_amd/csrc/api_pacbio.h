@@ -20,6 +20,9 @@ static PacbioHostModel setup_pacbio_model(jk_session& s, const jk_pacbio_args& a
     set_compression(s, a.compress, a.comp_method);
     if (!a.chi2_params_n || !a.chi2_params_s || !a.sqrt_params || !a.norm_params) throw Error(JK_ERR_ARG, "PacBio parameter vectors must not be NULL");
     s.pacbio = true; s.paired = false; s.n_ends = 1;
+    // (tests: start with too little per-launch scratch / image so that the run has to be planned again)
+    if (const char* e = std::getenv("JK_PB_POOL_SCALE")) { const double v = std::atof(e); if (v > 0) s.pool_scale = v; }
+    if (const char* e = std::getenv("JK_PB_IMAGE_SCALE")) { const double v = std::atof(e); if (v > 0) s.image_scale = v; }
     s.out_prefix = a.out_prefix ? a.out_prefix : "";
     s.abort_flag = a.abort_flag;
     s.device = a.device;
@@ -180,7 +183,7 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
         s.batches.push_back(b);
     }
     // the image: expected bytes + 12.5 % + 64 MB (pb_emit_kernel refuses to write past it: JK_KERR_IMAGE_FULL)
-    auto image_for = [&](uint64_t reads) { const uint64_t v = (uint64_t)((double)(reads * rec_mean) * s.image_scale); return v + v / 8 + (64ULL << 20); };
+    auto image_for = [&](uint64_t reads) { const uint64_t v = reads * rec_mean; return (uint64_t)((double)(v + v / 8 + (64ULL << 20)) * s.image_scale); };
     s.out_cap = image_for(total_reads);
     s.img_cap = image_for(max_reads);
     // event masks: 16 bytes per 64 positions of a read's walk (about its length), taken from the arena in chunks per wave
@@ -196,7 +199,7 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
         max_waves = std::max<uint64_t>(max_waves, (b.n_lanes + wl - 1) / wl);
     }
     // (every wave may leave most of its last chunk unused)
-    s.pb_mask_cap = (uint64_t)((double)(max_reads * blocks_per_read) * s.pool_scale) + (max_waves + 1) * PB_MASK_CHUNK;
+    s.pb_mask_cap = (uint64_t)((double)(max_reads * blocks_per_read + (max_waves + 1) * PB_MASK_CHUNK) * s.pool_scale);
     s.pb_stale_cap = (uint32_t)std::min<double>((double)(1u << 30), (double)(1u << 20) * s.pool_scale);
     const uint64_t sets = s.batches.size() > 1 ? 2 : 1;
     {

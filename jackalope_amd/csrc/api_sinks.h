@@ -93,20 +93,32 @@ struct EventPair {       // a timing pair that cannot leak when a HIP call betwe
 // Works through the input in groups of blocks so that the slot scratch stays at 512 MiB.  A streamed file is
 // made of several such pieces (one per generator launch, the last block of each shorter than 0xff00), closed
 // by one end-of-file block.
+// Scratch of bgzf_deflate_device.  A sink that compresses piece after piece keeps one (hipMalloc / hipFree synchronise the
+// whole device and the driver clears fresh VRAM: per piece they would stall the generator the sink runs beside).
+struct BgzfScratch {
+    DevBuf slots, sizes, offs, sums, base;
+    void reserve(uint64_t g_blocks, uint64_t n_groups) {
+        if (slots.n < g_blocks * BGZF_SLOT) slots.alloc(g_blocks * BGZF_SLOT);
+        if (sizes.n < g_blocks * 8) sizes.alloc(g_blocks * 8);
+        if (offs.n < g_blocks * 8) offs.alloc(g_blocks * 8);
+        const uint64_t sb = ((g_blocks + SCAN_BLOCK - 1) / SCAN_BLOCK) * 8;
+        if (sums.n < sb) sums.alloc(sb);
+        if (base.n < (n_groups + 1) * 8) base.alloc((n_groups + 1) * 8);
+    }
+};
 static uint64_t bgzf_deflate_device(int device, hipStream_t stream, const uint8_t* d_src, uint64_t n, uint8_t* d_dst,
-                                    uint64_t cap, double* ms, bool with_eof = true) {
+                                    uint64_t cap, double* ms, bool with_eof = true, BgzfScratch* keep = nullptr) {
     if (reinterpret_cast<uintptr_t>(d_src) & 15u) throw Error(JK_ERR_ARG, "BGZF input must be 16-byte aligned");
     if (cap < bgzf_bound(n)) throw Error(JK_ERR_ARG, "BGZF destination smaller than jk_bgzf_bound()");
     const BgzfTables T = bgzf_tables(device);
     const uint64_t n_blocks = (n + BGZF_BLOCK_IN - 1) / BGZF_BLOCK_IN;
     const uint64_t GROUP = 8192;
     const uint64_t n_groups = (n_blocks + GROUP - 1) / GROUP;
-    DevBuf slots, sizes, offs, sums, base;
+    BgzfScratch own;
+    BgzfScratch& sc = keep ? *keep : own;
     const uint64_t g_blocks = std::min<uint64_t>(GROUP, std::max<uint64_t>(n_blocks, 1));
-    slots.alloc(g_blocks * BGZF_SLOT);
-    sizes.alloc(g_blocks * 8); offs.alloc(g_blocks * 8);
-    sums.alloc(((g_blocks + SCAN_BLOCK - 1) / SCAN_BLOCK) * 8);
-    base.alloc((n_groups + 1) * 8);
+    sc.reserve(g_blocks, n_groups);
+    DevBuf &slots = sc.slots, &sizes = sc.sizes, &offs = sc.offs, &sums = sc.sums, &base = sc.base;
     JK_HIP(hipMemsetAsync(base.p, 0, (n_groups + 1) * 8, stream));
     EventPair ev;
     JK_HIP(hipEventRecord(ev.a, stream));
@@ -168,12 +180,13 @@ public:
         std::deque<Fl> flight;
         auto land = [&]() {
             const Fl f = flight.front(); flight.pop_front();
+            // (the buffer goes back to the ring on every path out of here, or to a worker together with its task)
+            struct Release { HostPipe* p; int k; bool armed; ~Release() { if (armed) p->release(k); } } rel{this, f.k, true};
             JK_HIP(hipEventSynchronize(ev_[f.k]));
             if (ordered || workers_.empty()) {
-                struct Release { HostPipe* p; int k; ~Release() { p->release(k); } } rel{this, f.k};
                 consume(static_cast<const uint8_t*>(buf_[f.k]), f.n, f.off);
             } else {
-                { std::lock_guard<std::mutex> l(m_); tasks_.push_back(Task{f.k, f.n, f.off, consume}); }
+                { std::lock_guard<std::mutex> l(m_); tasks_.push_back(Task{f.k, f.n, f.off, consume}); rel.armed = false; }
                 cv_.notify_all();
             }
         };
@@ -199,6 +212,13 @@ public:
         cv_.wait(l, [&] { return tasks_.empty() && running_ == 0; });
         if (!err_.empty()) { const std::string e = err_; err_.clear(); throw Error(JK_ERR_IO, e); }
     }
+    // the same without the error: for the exit paths that are already reporting one (files must not be closed, nor their
+    // names reopened, while a writer thread still holds a task with the old descriptor)
+    void quiesce() noexcept {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return tasks_.empty() && running_ == 0; });
+        err_.clear();
+    }
 private:
     struct Task { int k; size_t n; uint64_t off; Consume fn; };
     void free_all() {
@@ -208,7 +228,7 @@ private:
     int acquire() {
         std::unique_lock<std::mutex> l(m_);
         for (;;) {
-            if (!err_.empty()) { const std::string e = err_; throw Error(JK_ERR_IO, e); }
+            if (!err_.empty()) { const std::string e = err_; err_.clear(); throw Error(JK_ERR_IO, e); }     // (reported once: the pipe outlives the run)
             for (int k = 0; k < nb_; k++) if (!busy_[k]) { busy_[k] = 1; return k; }
             cv_.wait(l);
         }
@@ -281,7 +301,7 @@ public:
             }, true);
         } else if (!s_.host_deflate) {
             if (comp_.n < bgzf_bound(n)) comp_.alloc(bgzf_bound(n) + (bgzf_bound(n) >> 3));
-            const uint64_t nc = bgzf_deflate_device(s_.device, pipe.stream(), d_img, n, comp_.as<uint8_t>(), comp_.n, nullptr, false);
+            const uint64_t nc = bgzf_deflate_device(s_.device, pipe.stream(), d_img, n, comp_.as<uint8_t>(), comp_.n, nullptr, false, &bgzf_scratch_);
             const uint64_t at = at_;
             at_ += nc;
             if (null) pipe.copy(comp_.as<uint8_t>(), nc, [](const uint8_t*, size_t, uint64_t) {}, true);
@@ -316,6 +336,7 @@ public:
         if (fd_ >= 0) { const int fd = fd_; fd_ = -1; if (::close(fd) != 0) throw Error(JK_ERR_IO, "error closing " + fn_); }
         if (gz_) { gzFile g = gz_; gz_ = nullptr; if (gzclose(g) != Z_OK) throw Error(JK_ERR_IO, "error closing " + fn_); }
     }
+    void set_length(uint64_t n) { if (fd_ >= 0 && ::ftruncate(fd_, (off_t)n) != 0) throw Error(JK_ERR_IO, "ftruncate of " + fn_ + " failed: " + std::strerror(errno)); }
     uint64_t bytes_written() const { return at_; }     // (gzip streams: not tracked)
     uint64_t plain_bytes() const { return plain_; }
     const std::string& name() const { return fn_; }
@@ -334,6 +355,7 @@ private:
     uint64_t at_ = 0;            // next byte of the file
     uint64_t plain_ = 0;         // FASTQ bytes taken so far
     DevBuf comp_;
+    BgzfScratch bgzf_scratch_;   // kept from piece to piece
 };
 
 static const size_t PIPE_PIECE = BGZF_IN * 512;      // 33.4 MB pieces, a whole number of BGZF blocks
@@ -358,6 +380,9 @@ static void write_shard(const jk_session& s, const uint64_t* file_offset) {
     HostPipe& pipe = session_pipe(s);
     for (uint32_t e = 0; e < s.n_ends; e++) {
         FastqFile f(s, e, "", false, file_offset[e]);
+        // the shared file is opened without truncation (the other shards write into it too): the shard that holds the run's
+        // last lane knows where the file ends and cuts off what an older, longer file of that name would leave behind
+        if (s.lane_end == s.n_lanes_total) f.set_length(file_offset[e] + s.bytes[e]);
         f.add(pipe, s.d_out[e].as<uint8_t>(), s.bytes[e]);
         f.finish(pipe);
     }

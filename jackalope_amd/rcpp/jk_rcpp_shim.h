@@ -120,6 +120,15 @@ struct Placement {
         if (devices.empty()) { const int n = jk_device_count(); for (int i = 0; i < n; i++) devices.push_back(i); }
         if (devices.empty()) Rcpp::stop("no MI355X device is visible to this R session");
         if (const char* e = std::getenv("JACKALOPE_HIP_LANES")) { const long long v = std::atoll(e); if (v >= 1) lanes = static_cast<uint64_t>(v); }
+        else if (lanes < 4096) {
+            // The trade-off is the user's: n_threads lanes reproduce the reference's files for that thread count, but an
+            // Illumina lane is ONE GPU thread -- a handful of them is slower than the CPU path (PacBio lanes are worked on by
+            // a whole wave each and do not mind).  Say so once per call instead of running slowly in silence.
+            Rcpp::warning("jackalope (HIP): n_threads = %d gives %d generator lane(s) -- the output equals the reference's for that "
+                          "thread count, but the GPU needs 2^16..2^20 lanes for Illumina reads. Set the environment variable "
+                          "JACKALOPE_HIP_LANES (e.g. 262144): the reads are then those of a reference run with that many threads.",
+                          static_cast<int>(lanes), static_cast<int>(lanes));
+        }
     }
 };
 

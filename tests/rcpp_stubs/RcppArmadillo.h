@@ -11,6 +11,7 @@ namespace rcpp_stub {
 extern std::vector<uint32_t> seed_queue;
 extern size_t seed_pos;
 extern int runif_thread_violations;      // runif called off the "R main thread"
+extern int warnings;                     // Rcpp::warning calls
 void mark_main_thread();
 bool on_main_thread();
 }
@@ -20,6 +21,7 @@ public:
     exception(const char* m, bool = true) : std::runtime_error(m) {}
 };
 inline void stop(const std::string& m) { throw exception(m.c_str(), false); }
+template <typename... A> inline void warning(const char*, A...) { rcpp_stub::warnings++; }
 struct NumericVector {
     std::vector<double> v;
     double operator[](int i) const { return v[(size_t)i]; }

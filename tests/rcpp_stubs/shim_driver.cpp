@@ -6,7 +6,7 @@
 namespace rcpp_stub {
 std::vector<uint32_t> seed_queue;
 size_t seed_pos = 0;
-int runif_thread_violations = 0, progress_thread_violations = 0;
+int runif_thread_violations = 0, progress_thread_violations = 0, warnings = 0;
 unsigned long long progress_max = 0, progress_shown = 0, abort_after = 0;
 static std::thread::id main_id;
 void mark_main_thread() { main_id = std::this_thread::get_id(); }
@@ -120,6 +120,7 @@ struct drv_pacbio {
 
 const char* drv_last_error(void) { return g_err.c_str(); }
 // {seed words drawn, runif calls off the main thread, progress calls off the main thread, progress shown, progress max}
+uint64_t drv_warnings(void) { return (uint64_t)rcpp_stub::warnings; }
 void drv_stats(uint64_t* out5) {
     out5[0] = rcpp_stub::seed_pos; out5[1] = (uint64_t)rcpp_stub::runif_thread_violations; out5[2] = (uint64_t)rcpp_stub::progress_thread_violations;
     out5[3] = rcpp_stub::progress_shown; out5[4] = rcpp_stub::progress_max;

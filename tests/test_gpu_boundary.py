@@ -171,6 +171,18 @@ def test_shim_illumina_ref(ja, O, hs25, drv, tmp_path):
     assert st["seeds"] == used and st["runif_off_main"] == 0 and st["progress_off_main"] == 0
     assert st["shown"] == st["max"] == n_reads
     assert read(pre + "_R1.fq") == o1 and read(pre + "_R2.fq") == o2
+    # 300 lanes reproduce the reference's 300-thread files but are far below what the GPU needs: the shim says so
+    # (Rcpp::warning) instead of running slowly in silence; with JACKALOPE_HIP_LANES set it has nothing to say
+    drv.drv_warnings.restype = C.c_uint64
+    w0 = drv.drv_warnings()
+    assert w0 >= 1
+    os.environ["JACKALOPE_HIP_LANES"] = str(T)
+    try:
+        assert drv.drv_illumina_ref(C.byref(gi), C.byref(a)) == 0, drv.drv_last_error()
+    finally:
+        del os.environ["JACKALOPE_HIP_LANES"]
+    assert drv.drv_warnings() == w0
+    assert read(pre + "_R1.fq") == o1
 
 
 def hap_oracle(O, hs, hs25, words, n_reads, T, probs, barcodes=()):

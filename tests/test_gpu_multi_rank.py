@@ -17,7 +17,9 @@ CASES = {
     # name: (chromosome sizes, n_haps, n_reads, T)
     "many_reads_per_lane": ([120_000, 60_000, 9_000], 3, 200_000, 1001),     # the speculated seed offsets hold
     "few_reads_per_lane": ([50_000, 20_000], 5, 3_000, 700),                  # haplotypes without reads: offsets are corrected
+    "pacbio": ([400_000, 150_000], 0, 1_500, 333),                            # pacbio() on the reference genome, one read end
 }
+PB = {"custom_read_lengths": [700, 2500, 6000]}
 
 
 def _free_port():
@@ -32,6 +34,8 @@ def _make(ja, case):
     from jackalope_amd.genome import random_haplotypes
     sizes, nh, n_reads, T = CASES[case]
     ref = ja.synthetic_genome(sizes, seed=61)
+    if nh == 0:
+        return ref, ja.seed_words(63, 16 * T + 64), n_reads, T
     hs = random_haplotypes(ref, nh, seed=62)
     words = ja.seed_words(63, hs.seed_budget(T) + 64)
     return hs, words, n_reads, T
@@ -51,9 +55,15 @@ def _worker(rank, world, port, tmpdir, case):
 
     def open_fn(lo, hi, off):
         opened.append(off)
+        if case == "pacbio":
+            return ja.pacbio(hs, prefix, n_reads, n_threads=T, seed_words=words, lane_begin=lo, lane_end=hi, seed_offset_words=off,
+                             _session=True, **PB)
         return ja.illumina(hs, prefix, n_reads, 150, True, n_threads=T, seed_words=words, lane_begin=lo, lane_end=hi,
                            seed_offset_words=off, _session=True)
-    s = open_shard(open_fn, T, n_reads // 2, 8 + 16 * hs.n_haps())
+    if case == "pacbio":
+        s = open_shard(open_fn, T, n_reads, 8)
+    else:
+        s = open_shard(open_fn, T, n_reads // 2, 8 + 16 * hs.n_haps())
     with s:
         s.generate()
         sizes, reads = s.sizes()
@@ -62,24 +72,36 @@ def _worker(rank, world, port, tmpdir, case):
         seed_range = s.shard_seed_words()
     dist.barrier()
     with open(os.path.join(tmpdir, "rank%d.txt" % rank), "w") as fh:
-        fh.write("%d %d %d %d %d %d" % (len(opened), seed_range[0], seed_range[1], totals[0], totals[1][0], totals[1][1]))
+        fh.write("%d %d %d %d %d %d" % (len(opened), seed_range[0], seed_range[1], totals[0], totals[1][0], totals[1][-1]))
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_two_ranks_on_one_gpu_write_the_single_process_files(ja, tmp_path, case):
+    # older, LONGER files of the same names are in the way (overwrite = TRUE): the ranks open the shared files without
+    # truncating them, so the rank that holds the last lane has to cut the old tail off
+    for e in (1, 2):
+        with open(tmp_path / ("shared_R%d.fq" % e), "wb") as fh:
+            fh.write(b"@stale\nACGT\n+\n!!!!\n" * 8_000_000)
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), case), nprocs=2, join=True)
     hs, words, n_reads, T = _make(ja, case)
-    with ja.illumina(hs, None, n_reads, 150, True, n_threads=T, seed_words=words, _session=True) as s:
-        s.generate()
-        r1, r2 = s.fetch(0), s.fetch(1)
-        used = s.seed_words_used()
-    assert open(tmp_path / "shared_R1.fq", "rb").read() == r1
-    assert open(tmp_path / "shared_R2.fq", "rb").read() == r2
+    if case == "pacbio":
+        with ja.pacbio(hs, None, n_reads, n_threads=T, seed_words=words, _session=True, **PB) as s:
+            s.generate()
+            r1 = r2 = s.fetch(0)
+            used = s.seed_words_used()
+        assert open(tmp_path / "shared_R1.fq", "rb").read() == r1
+    else:
+        with ja.illumina(hs, None, n_reads, 150, True, n_threads=T, seed_words=words, _session=True) as s:
+            s.generate()
+            r1, r2 = s.fetch(0), s.fetch(1)
+            used = s.seed_words_used()
+        assert open(tmp_path / "shared_R1.fq", "rb").read() == r1
+        assert open(tmp_path / "shared_R2.fq", "rb").read() == r2
     info = [[int(x) for x in open(tmp_path / ("rank%d.txt" % r)).read().split()] for r in range(2)]
     assert info[0][1] == 8 * T and info[0][2] == info[1][1] and info[1][2] == used      # the ranks' seed ranges chain up
     assert info[0][3:] == info[1][3:] == [n_reads, len(r1), len(r2)]
-    if case == "many_reads_per_lane":
+    if case != "few_reads_per_lane":
         assert info[0][0] == 1 and info[1][0] == 1        # nobody had to open twice
     else:
         assert info[1][0] == 2                            # rank 1's speculated offset was wrong and was corrected

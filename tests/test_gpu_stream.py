@@ -169,3 +169,29 @@ def test_job_progress_and_abort(ja, tmp_path):
         jb.run()
         assert jb.progress() == (n_reads, n_reads)
     assert read(str(tmp_path / "k") + "_R1.fq").count(b"\n") == 4 * (n_reads // 2)
+
+
+@pytest.mark.parametrize("compress", [False, True])
+def test_streamed_pacbio_survives_a_replan(ja, O, tmp_path, compress):
+    """A streaming run whose scratch (or image) turns out too small is planned again, larger, and run again INTO THE SAME
+    FILES: the first attempt's sink must be quiet -- no writer thread still holding a task with the old descriptor -- before
+    the files are closed and their names reopened (the sink's pipe outlives the attempt), or old bytes land in the new
+    file.  Plain (pwrite at offsets) and device BGZF (compressed offsets change with the launch layout)."""
+    g = ja.synthetic_genome([900_000, 300_000], seed=71)
+    n_reads, T = 3000, 600
+    words = ja.seed_words(91, 16 * T)
+    pb = {"custom_read_lengths": [3000, 9000, 20000]}
+    o, _, _ = O.pacbio_ref(g, pb, n_reads=n_reads, n_threads=T, words=words)
+    for var, val in (("JK_PB_POOL_SCALE", "0.05"), ("JK_PB_IMAGE_SCALE", "0.05")):
+        pre = str(tmp_path / ("p" + var[-11:-6] + str(int(compress))))
+        os.environ[var] = val
+        try:
+            with ja.pacbio(g, pre, n_reads, n_threads=T, seed_words=words, max_batch_bytes=8 << 20, compress=compress, _session=True,
+                           stream_output=True, **pb) as s:
+                s.run()
+                assert s.retries() >= 1, var
+                assert s.sizes() == ([len(o)], n_reads)
+        finally:
+            del os.environ[var]
+        raw = read(pre + "_R1.fq" + (".gz" if compress else ""))
+        assert (gzip.decompress(raw) if compress else raw) == o, var
