@@ -353,6 +353,7 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, launch_lanes, lane_cap, lp, Q, 0, first_lanes);
     const IlluminaPacked packed = pack_illumina_tables(s.tables);
     s.d_tab.upload(packed.tab);
+    s.d_tab_lo.upload(packed.lo);
     s.d_mm2.upload(packed.mm2);
     s.evw_set = (size_t)s.n_ends * 4 * s.ev_words * std::max<uint32_t>(max_lanes, 1);      // u64 words per generator in flight
     s.d_evw.alloc(2 * s.evw_set * 8);
@@ -393,7 +394,7 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     P.g.nflags = s.d_nflags.p ? s.d_nflags.as<uint8_t>() : nullptr;
     P.evw = s.d_evw.as<uint64_t>();
     P.err = s.d_err.as<uint32_t>();
-    P.tab = s.d_tab.as<uint32_t>(); P.mm2 = s.d_mm2.as<uint64_t>();
+    P.tab = s.d_tab.as<uint32_t>(); P.mm2 = s.d_mm2.as<uint64_t>(); P.tab_lo = s.d_tab_lo.as<uint32_t>();
     P.n_info = (uint32_t)s.tables.info.size(); P.n_entries = (uint32_t)s.tables.thresh.size();
 
     P.lds_seg_off = s.lds_seg_off;

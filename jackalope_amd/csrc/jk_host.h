@@ -329,28 +329,34 @@ struct IlluminaTables {
 // The same tables in the form the kernel reads (one LDS/L2 access per step of a base, no unpacking arithmetic):
 //   mm2   [256] u64, indexed by the quality CHARACTER c = (q + 33) & 255 (what fill_read_qual emits): mm_thresh[q]
 //   tab   one blob of u32: info2 [end][pos][nt] {byte offset of the position's first alias entry in the blob,
-//         number of entries}, then per alias entry {thresh lo, thresh hi, 8*char if kept | 8*char of the alias << 16}
+//         number of entries}, then per alias entry {HIGH word of its cut point, 8*char if kept | 8*char of the alias << 16}
 //         (8*char = byte offset of the character's cut point in mm2)
+//   lo    per alias entry the LOW word of its cut point.  `u < Prob[i]` (src/alias_sampler.h:57) is `x < cut point` on
+//         the raw 64-bit draw; the high words decide it unless they are equal (2^-32 per draw), and only then does the
+//         kernel fetch the low word, from global memory, behind a wave-uniform branch.  8 bytes per entry instead of 12:
+//         the pair of HiSeq 2500 / 125 bp profiles (20 218 entries) and GA II / 75 bp fit in LDS, which they did not.
 struct IlluminaPacked {
     std::vector<uint64_t> mm2;
     std::vector<uint32_t> tab;
+    std::vector<uint32_t> lo;
 };
 inline IlluminaPacked pack_illumina_tables(const IlluminaTables& T) {
     IlluminaPacked K;
     K.mm2.assign(256, 0);
     for (uint32_t q = 0; q < 256; q++) K.mm2[(q + 33u) & 255u] = T.mm_thresh[q];
     const size_t n_info = T.info.size(), n_ent = T.thresh.size();
-    K.tab.resize(n_info * 2 + n_ent * 3);
+    K.tab.resize(n_info * 2 + n_ent * 2);
+    K.lo.resize(std::max<size_t>(n_ent, 1));
     for (size_t i = 0; i < n_info; i++) {
-        K.tab[2 * i] = (uint32_t)(n_info * 8) + (T.info[i] & 0xffffffu) * 12u;
+        K.tab[2 * i] = (uint32_t)(n_info * 8) + (T.info[i] & 0xffffffu) * 8u;
         K.tab[2 * i + 1] = T.info[i] >> 24;
     }
     uint32_t* ent = K.tab.data() + n_info * 2;
     for (size_t e = 0; e < n_ent; e++) {
-        ent[3 * e] = (uint32_t)T.thresh[e];
-        ent[3 * e + 1] = (uint32_t)(T.thresh[e] >> 32);
+        K.lo[e] = (uint32_t)T.thresh[e];
+        ent[2 * e] = (uint32_t)(T.thresh[e] >> 32);
         const uint32_t c_self = ((T.quals[e] & 0xffu) + 33u) & 255u, c_alias = ((T.quals[e] >> 8) + 33u) & 255u;
-        ent[3 * e + 2] = (c_self * 8u) | ((c_alias * 8u) << 16);
+        ent[2 * e + 1] = (c_self * 8u) | ((c_alias * 8u) << 16);
     }
     return K;
 }

@@ -117,8 +117,9 @@ struct IlluminaKernelParams {
     uint32_t bc_len; uint8_t barcode[JK_MAX_BARCODE];      // encoded like the genome
     // tables, see IlluminaPacked in jk_host.h: mm2 [256] u64 by quality character (always staged to LDS);
     // tab = info2 [end][pos][nt] {byte offset of the first alias entry in tab, n entries} followed by the alias
-    // entries {thresh lo, thresh hi, 8*char kept | 8*char of the alias << 16} (staged to LDS when LDS_TAB)
-    const uint32_t* tab; const uint64_t* mm2;
+    // entries {cut point's high word, 8*char kept | 8*char of the alias << 16} (staged to LDS when LDS_TAB); tab_lo: the cut
+    // points' low words, one per entry, read when a draw's high word equals its entry's (global memory)
+    const uint32_t* tab; const uint64_t* mm2; const uint32_t* tab_lo;
     uint32_t n_info, n_entries;
     uint32_t lds_seg_off;                                  // HAP: byte offset of the per-lane segment table in LDS
     uint32_t lds_lut_off;                                  // packed reference: byte offset of the 512-entry expansion table in LDS
@@ -371,7 +372,7 @@ illumina_kernel(IlluminaKernelParams P) {
 #endif
     if (LDS_TAB) {
         uint32_t* s_tab = reinterpret_cast<uint32_t*>(smem);
-        const uint32_t n_words = 2u * P.n_info + 3u * P.n_entries;
+        const uint32_t n_words = 2u * P.n_info + 2u * P.n_entries;
         // entry offsets become absolute LDS addresses on the way in (one add less per base)
         const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
         for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x)
@@ -388,6 +389,8 @@ illumina_kernel(IlluminaKernelParams P) {
         T.tab = reinterpret_cast<const uint8_t*>(P.tab);
     }
     const bool info_lds = LDS_TAB || P.info_in_lds;
+    // offset of the first alias entry, in the units of the info table's entry offsets (absolute LDS addresses when LDS_TAB)
+    const uint32_t ent_base = 8u * P.n_info + (LDS_TAB ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem : 0u);
     // packed reference: 8 bits (4 bases, ascending source order) -> the 4 code bytes in read order; entries 256..511 for
     // the reverse strand (descending source order, complemented: code ^ 2)
     if (!SEG && P.lds_cell_off != 0xffffffffu) reinterpret_cast<uint32_t*>(smem + P.lds_cell_off)[threadIdx.x] = 0;     // chromosome cache: empty
@@ -841,18 +844,25 @@ illumina_kernel(IlluminaKernelParams P) {
                 const uint2 inf = info_lds ? *reinterpret_cast<const uint2*>(smem + inf_off) : *reinterpret_cast<const uint2*>(T.tab + inf_off);
                 const uint32_t ent_off = inf.x, nq = inf.y;
                 const uint32_t idx = alias_index32(x1, nq);
-                uint32_t e0, e1, qp;
+                const uint32_t eoff = idx * 8u + ent_off;
+                uint32_t th_hi, qp;
                 if (LDS_TAB) {
-                    const __attribute__((address_space(3))) uint32_t* ep = (const __attribute__((address_space(3))) uint32_t*)(uintptr_t)(__umul24(idx, 12u) + ent_off);
-                    e0 = ep[0]; e1 = ep[1]; qp = ep[2];
+                    const __attribute__((address_space(3))) uint32_t* ep = (const __attribute__((address_space(3))) uint32_t*)(uintptr_t)eoff;
+                    th_hi = ep[0]; qp = ep[1];
                 } else {
-                    const uint32_t* ep = reinterpret_cast<const uint32_t*>(T.tab + (__umul24(idx, 12u) + ent_off));
-                    e0 = ep[0]; e1 = ep[1]; qp = ep[2];
+                    const uint2 ev2 = *reinterpret_cast<const uint2*>(T.tab + eoff);
+                    th_hi = ev2.x; qp = ev2.y;
                 }
-                const uint64_t th = ((uint64_t)e1 << 32) | e0;
                 const uint64_t x2 = rng();
                 const uint64_t x3 = rng();
-                const uint32_t ch8 = (x2 < th) ? (qp & 0xffffu) : (qp >> 16);
+                // u < Prob[i]  <=>  x2 < cut point: decided by the high words unless they are equal (2^-32 per draw)
+                const uint32_t x2h = (uint32_t)(x2 >> 32);
+                bool keep = x2h < th_hi;
+                if (__builtin_amdgcn_ballot_w64(x2h == th_hi) != 0) {
+                    asm volatile("" ::: "memory");
+                    if (x2h == th_hi) keep = (uint32_t)x2 < P.tab_lo[(eoff - ent_base) >> 3];
+                }
+                const uint32_t ch8 = keep ? (qp & 0xffffu) : (qp >> 16);
                 const uint64_t mmth = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(s_mm) + ch8);
                 mism = x3 < mmth;
                 return ch8;

@@ -29,7 +29,7 @@ struct jk_session {
     uint32_t n_chroms = 0;
     // tables
     IlluminaTables tables;
-    DevBuf d_tab, d_mm2;
+    DevBuf d_tab, d_tab_lo, d_mm2;
     bool lds_tables = false;
     size_t lds_bytes = 0, lds_launch = 0, evw_set = 0;
     uint32_t lds_seg_off = 0, lds_lut_off = 0, lds_cell_off = 0xffffffffu;
