@@ -191,6 +191,13 @@ typedef struct jk_pacbio_args {
 const char* jk_last_error(void);
 const char* jk_version(void);
 int jk_device_count(void);                /* MI355X devices visible to this process (0 when there is none) */
+/* The device arena: large device buffers (read pools, FASTQ images, genome) of a closed session stay allocated and are
+   reused by the next session of the process -- the next haplotype of write_reads_cpp_sep_files_'s loop
+   (/root/reference/src/hts.h:512-552 opens a writer per haplotype), the next call from R -- instead of going through the
+   driver's allocator, which clears memory it hands out.  Parked memory is released when an allocation needs it, on
+   jk_device_arena_trim (device < 0: every device) and at process exit; JK_ARENA=0 in the environment turns the arena off. */
+void jk_device_arena_trim(int device);
+void jk_device_arena_stats(int device, uint64_t* parked_bytes, uint64_t* hits, uint64_t* misses);
 
 /* One-shot entry points: generate and write the FASTQ files, like the reference's functions. */
 int jk_illumina_ref(const jk_ref_genome* genome, const jk_illumina_args* args);

@@ -109,7 +109,7 @@ class PacbioArgs(C.Structure):
 
 # every symbol include/jackalope_hip.h declares
 EXPORTS = [
-    "jk_last_error", "jk_version", "jk_device_count", "jk_illumina_ref", "jk_illumina_hap", "jk_pacbio_ref", "jk_pacbio_hap",
+    "jk_last_error", "jk_version", "jk_device_count", "jk_device_arena_trim", "jk_device_arena_stats", "jk_illumina_ref", "jk_illumina_hap", "jk_pacbio_ref", "jk_pacbio_hap",
     "jk_illumina_ref_job", "jk_illumina_hap_job", "jk_pacbio_ref_job", "jk_pacbio_hap_job", "jk_job_n_files", "jk_job_plan_next", "jk_job_run",
     "jk_job_progress", "jk_job_seed_words_used", "jk_job_free",
     "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_pacbio_ref_open", "jk_pacbio_hap_open", "jk_session_generate", "jk_session_run", "jk_session_progress", "jk_session_sizes",

@@ -210,7 +210,7 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
         plan(~0ULL);
         if (max_pool > (8ULL << 30)) {
             size_t free_b = 0, total_b = 0;
-            JK_HIP(hipMemGetInfo(&free_b, &total_b));
+            dev_mem_info(&free_b, &total_b);
             uint64_t image = image_hint ? std::min<uint64_t>(out_cap, image_hint + image_hint / 8 + (64ULL << 20)) : out_cap;
             if (s.streaming) image = 2 * max_pool;                 // two per-batch images instead of the whole run's
             const uint64_t need = (2 * max_pool + image) * s.n_ends + (16ULL << 30);
@@ -222,7 +222,7 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     {   // say what does not fit before hipMalloc does (a tile's pools are 64 x its largest lane: few lanes with many
         // reads each need far more pool than their FASTQ)
         size_t free_b = 0, total_b = 0;
-        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        dev_mem_info(&free_b, &total_b);
         const uint64_t sets = s.batches.size() > 1 ? 2 : 1;
         const uint64_t image = s.streaming ? std::min<uint64_t>(sets, 2) * (max_pool + 64) : out_cap;
         const uint64_t need = (sets * (max_pool + 64 + CP_SLACK) + image + 64) * s.n_ends + s.n_shard * 64;
@@ -268,7 +268,7 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     if (want_sets <= 1) s.n_pool_sets = 1;
     if (s.batches.size() > 2 && want_sets >= 3) {
         size_t free_b = 0, total_b = 0;
-        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        dev_mem_info(&free_b, &total_b);
         if (free_b > (max_pool + 64 + CP_SLACK) * s.n_ends + total_b / 16) {
             for (uint32_t e = 0; e < s.n_ends; e++) s.d_pool[2][e].alloc(max_pool + 64 + CP_SLACK);
             s.n_pool_sets = 3;
@@ -302,7 +302,7 @@ static void pack_reference(jk_session& s) {
     if (blocks > 0x7fffffffULL) return;
     {   // an extra, not a need: a run that has filled the device with pools and image goes without it
         size_t free_b = 0, total_b = 0;
-        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        dev_mem_info(&free_b, &total_b);
         if ((uint64_t)free_b < blocks * 1024 + (2ULL << 30)) return;
     }
     s.d_packed.alloc(blocks * 1024 + 64);
@@ -610,7 +610,7 @@ static void materialise_haplotypes(jk_session& s, uint64_t n_cells, const std::v
     JK_HIP(hipGetLastError());
     JK_HIP(hipDeviceSynchronize());
     s.d_seq.release(); s.d_mut.release(); s.d_bucket.release(); s.d_bucket_off.release(); s.d_cell_off.release();
-    std::swap(s.d_seq.p, d_hap.p); std::swap(s.d_seq.n, d_hap.n);
+    s.d_seq.swap(d_hap);
     s.d_chrom_off.upload(out_off);           // indexed by cell from here on
     s.hap_materialised = true;
 }
@@ -688,7 +688,7 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
         const uint64_t pools = 2 * s.n_ends * std::min<uint64_t>(launch * (reads_lane_max / s.n_ends) * rec, a.max_batch_bytes ? a.max_batch_bytes : ~0ULL);
         const uint64_t image = s.streaming ? 0 : (reads_shard / s.n_ends) * rec * s.n_ends;
         size_t free_b = 0, total_b = 0;
-        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        dev_mem_info(&free_b, &total_b);
         bool want = mat + pools + image + (12ULL << 30) <= free_b;
         if (const char* e = std::getenv("JK_HAP_MATERIALISE")) want = std::atoi(e) != 0;
         if (want) materialise_haplotypes(s, n_cells, cell_size);

@@ -204,7 +204,7 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     const uint64_t sets = s.batches.size() > 1 ? 2 : 1;
     {
         size_t free_b = 0, total_b = 0;
-        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        dev_mem_info(&free_b, &total_b);
         const uint64_t image = s.streaming ? sets * s.img_cap : s.out_cap;
         const uint64_t scratch = sets * (s.pb_mask_cap * 16 + max_reads * sizeof(PbRead) + s.pb_stale_cap);
         // (buffers of an earlier plan of this session are released below before the new ones are made)
@@ -356,7 +356,7 @@ static void open_pacbio_hap(jk_session& s, const jk_hap_set& hs, const jk_pacbio
         const uint64_t rec = max_hdr + 24 + 2 * (uint64_t)std::ceil(M.len_mean);
         const uint64_t image = std::min<uint64_t>(reads_shard * rec, s.streaming ? (40ULL << 30) : ~0ULL);
         size_t free_b = 0, total_b = 0;
-        JK_HIP(hipMemGetInfo(&free_b, &total_b));
+        dev_mem_info(&free_b, &total_b);
         bool want = mat + image + image / 4 + (12ULL << 30) <= free_b;
         if (const char* e = std::getenv("JK_HAP_MATERIALISE")) want = std::atoi(e) != 0;
         if (want) materialise_haplotypes(s, n_cells, cell_size);

@@ -83,6 +83,14 @@ extern "C" {
 const char* jk_last_error(void) { return g_last_error.c_str(); }
 const char* jk_version(void) { return "jackalope_hip 0.2 (gfx950)"; }
 int jk_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+void jk_device_arena_trim(int device) { DevArena::get().trim(device); }
+void jk_device_arena_stats(int device, uint64_t* bytes, uint64_t* hits, uint64_t* misses) {
+    DevArena& a = DevArena::get();
+    if (bytes) *bytes = a.bytes(device);
+    std::lock_guard<std::mutex> l(a.m);
+    if (hits) *hits = a.hits;
+    if (misses) *misses = a.misses;
+}
 #ifdef JK_TIMELINE
 int jk_debug_timeline(uint64_t* out, uint64_t n_words) {     // experiment builds only
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(jk::g_timeline), n_words * 8) == hipSuccess ? 0 : 1;

@@ -195,3 +195,24 @@ def test_streamed_pacbio_survives_a_replan(ja, O, tmp_path, compress):
             del os.environ[var]
         raw = read(pre + "_R1.fq" + (".gz" if compress else ""))
         assert (gzip.decompress(raw) if compress else raw) == o, var
+
+
+def test_two_jobs_in_one_process_share_the_device_arena(ja, hs25, tmp_path):
+    """The per-haplotype loop of sep_files (src/hts.h:512-552) and repeated calls from one R session open session after
+    session: the large device buffers of a closed session are parked and the next session of the same shape takes them
+    instead of going through hipMalloc (which clears fresh VRAM: seconds for a 100 GB run).  Same files both times."""
+    g = ja.synthetic_genome([2_000_000], seed=23)
+    n_reads, T = 2_000_000, 65536
+    words = ja.seed_words(79, 16 * T)
+    ja.arena_trim()
+    pre = [str(tmp_path / "j0"), str(tmp_path / "j1")]
+    ja.illumina(g, pre[0], n_reads, 150, True, n_threads=T, seed_words=words)
+    st0 = ja.arena_stats()
+    assert st0["bytes"] > 100 << 20              # pools and image slots of the closed session are parked
+    ja.illumina(g, pre[1], n_reads, 150, True, n_threads=T, seed_words=words)
+    st1 = ja.arena_stats()
+    assert st1["hits"] >= st0["hits"] + 4 and st1["bytes"] == st0["bytes"]      # ... and were taken again, not re-made
+    for e in (1, 2):
+        assert read("%s_R%d.fq" % (pre[0], e)) == read("%s_R%d.fq" % (pre[1], e))
+    ja.arena_trim()
+    assert ja.arena_stats()["bytes"] == 0
