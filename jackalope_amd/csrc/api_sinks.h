@@ -126,8 +126,12 @@ static uint64_t bgzf_deflate_device(int device, hipStream_t stream, const uint8_
         const uint64_t b0 = g * GROUP;
         const uint32_t nb = (uint32_t)std::min<uint64_t>(GROUP, n_blocks - b0);
         const uint64_t off = b0 * BGZF_BLOCK_IN;
-        hipLaunchKernelGGL(bgzf_deflate_kernel, dim3(nb), dim3(BGZF_THREADS), 0, stream, d_src + off, n - off,
-                           slots.as<uint8_t>(), sizes.as<uint64_t>(), T);
+        // matches (same column of the previous record, runs) unless JK_BGZF_LZ=0: literals only
+        static const bool lz = !(std::getenv("JK_BGZF_LZ") && std::atoi(std::getenv("JK_BGZF_LZ")) == 0);
+        if (lz) hipLaunchKernelGGL(bgzf_deflate_lz_kernel, dim3(nb), dim3(BGZF_THREADS), 0, stream, d_src + off, n - off,
+                                   slots.as<uint8_t>(), sizes.as<uint64_t>(), T);
+        else hipLaunchKernelGGL(bgzf_deflate_kernel, dim3(nb), dim3(BGZF_THREADS), 0, stream, d_src + off, n - off,
+                                slots.as<uint8_t>(), sizes.as<uint64_t>(), T);
         const uint32_t nsb = (nb + SCAN_BLOCK - 1) / SCAN_BLOCK;
         hipLaunchKernelGGL(scan_block_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, stream, sizes.as<uint64_t>(), offs.as<uint64_t>(),
                            sums.as<uint64_t>(), nb);
