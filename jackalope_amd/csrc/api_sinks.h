@@ -287,10 +287,18 @@ public:
     }
     FastqFile(const FastqFile&) = delete;
     FastqFile& operator=(const FastqFile&) = delete;
-    ~FastqFile() { if (fd_ >= 0) ::close(fd_); if (gz_) gzclose(gz_); }
+    ~FastqFile() {
+        // (no thread may hold a task with this file's descriptor when it closes: the copier first, then the pipe's writers)
+        stop_copier();
+        if (pipe_) pipe_->quiesce();
+        if (zstream_) (void)hipStreamDestroy(zstream_);
+        if (fd_ >= 0) ::close(fd_);
+        if (gz_) gzclose(gz_);
+    }
 
     // n bytes of FASTQ at d_img (device); pieces of one file must be added in file order
     void add(HostPipe& pipe, const uint8_t* d_img, uint64_t n) {
+        pipe_ = &pipe;
         if (n == 0) return;
         plain_ += n;
         const int fd = fd_; const std::string fn = fn_; const bool null = null_;
@@ -304,13 +312,29 @@ public:
                 if (!null_ && gzwrite(gz_, p, (unsigned)cnt) != (int)cnt) throw Error(JK_ERR_IO, "gzwrite to " + fn_ + " failed");
             }, true);
         } else if (!s_.host_deflate) {
-            if (comp_.n < bgzf_bound(n)) comp_.alloc(bgzf_bound(n) + (bgzf_bound(n) >> 3));
-            const uint64_t nc = bgzf_deflate_device(s_.device, pipe.stream(), d_img, n, comp_.as<uint8_t>(), comp_.n, nullptr, false, &bgzf_scratch_);
+            // Two stages.  This thread compresses the piece where it lies (its own stream; the image slot is free again
+            // when add() returns); a copier thread brings the compressed bytes to the host and on to the writer threads
+            // while the next piece -- the other read end, the next launch -- is being generated and compressed.  Two
+            // compressed buffers in rotation: piece k waits for the copy of piece k - 2.
+            if (!zstream_) JK_HIP(hipStreamCreateWithFlags(&zstream_, hipStreamNonBlocking));
+            const int kb = (int)(n_pieces_++ & 1u);
+            {
+                std::unique_lock<std::mutex> l(cm_);
+                ccv_.wait(l, [&] { return !cbusy_[kb] || !cerr_.empty(); });
+                if (!cerr_.empty()) { const std::string e = cerr_; cerr_.clear(); throw Error(JK_ERR_IO, e); }
+            }
+            DevBuf& comp = comp_[kb];
+            if (comp.n < bgzf_bound(n)) comp.alloc(bgzf_bound(n) + (bgzf_bound(n) >> 3));
+            const uint64_t nc = bgzf_deflate_device(s_.device, zstream_, d_img, n, comp.as<uint8_t>(), comp.n, nullptr, false, &bgzf_scratch_);
             const uint64_t at = at_;
             at_ += nc;
-            if (null) pipe.copy(comp_.as<uint8_t>(), nc, [](const uint8_t*, size_t, uint64_t) {}, true);
-            else pipe.copy(comp_.as<uint8_t>(), nc, [fd, fn, at](const uint8_t* p, size_t cnt, uint64_t off) { pwrite_all(fd, fn, p, cnt, at + off); }, false);
-            pipe.drain();            // comp_ is reused by the next piece
+            {
+                std::lock_guard<std::mutex> l(cm_);
+                cbusy_[kb] = true;
+                cq_.push_back(CopyTask{kb, nc, at});
+                if (!copier_.joinable()) copier_ = std::thread([this, &pipe] { copy_loop(pipe); });
+            }
+            ccv_.notify_all();
         } else {
             const unsigned n_thr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
             pipe.copy(d_img, n, [&](const uint8_t* buf, size_t cnt, uint64_t) {
@@ -335,6 +359,11 @@ public:
     }
     // all pieces are in: end-of-file block (unless another part follows in the same file), close
     void finish(HostPipe& pipe, bool with_eof = true) {
+        {   // every compressed piece has left the device
+            std::unique_lock<std::mutex> l(cm_);
+            ccv_.wait(l, [&] { return (cq_.empty() && !cbusy_[0] && !cbusy_[1]) || !cerr_.empty(); });
+            if (!cerr_.empty()) { const std::string e = cerr_; cerr_.clear(); throw Error(JK_ERR_IO, e); }
+        }
         pipe.drain();
         if (s_.compress > 0 && s_.bgzip && with_eof) { if (!null_) pwrite_all(fd_, fn_, kBgzfEof, sizeof(kBgzfEof), at_); at_ += sizeof(kBgzfEof); }
         if (fd_ >= 0) { const int fd = fd_; fd_ = -1; if (::close(fd) != 0) throw Error(JK_ERR_IO, "error closing " + fn_); }
@@ -352,14 +381,48 @@ public:
         }
     }
 private:
+    struct CopyTask { int buf; uint64_t n; uint64_t at; };
+    void copy_loop(HostPipe& pipe) {
+        (void)hipSetDevice(s_.device);
+        for (;;) {
+            CopyTask k;
+            {
+                std::unique_lock<std::mutex> l(cm_);
+                ccv_.wait(l, [&] { return cstop_ || !cq_.empty(); });
+                if (cq_.empty()) return;
+                k = cq_.front(); cq_.pop_front();
+            }
+            std::string err;
+            try {
+                const int fd = fd_; const std::string fn = fn_; const uint64_t at = k.at;
+                if (null_) pipe.copy(comp_[k.buf].as<uint8_t>(), k.n, [](const uint8_t*, size_t, uint64_t) {}, true);
+                else pipe.copy(comp_[k.buf].as<uint8_t>(), k.n, [fd, fn, at](const uint8_t* p, size_t cnt, uint64_t off) { pwrite_all(fd, fn, p, cnt, at + off); }, false);
+            } catch (const std::exception& e) { err = e.what(); }
+            { std::lock_guard<std::mutex> l(cm_); cbusy_[k.buf] = false; if (!err.empty() && cerr_.empty()) cerr_ = err; }
+            ccv_.notify_all();
+        }
+    }
+    void stop_copier() {
+        { std::lock_guard<std::mutex> l(cm_); cstop_ = true; cq_.clear(); }
+        ccv_.notify_all();
+        if (copier_.joinable()) copier_.join();
+    }
     const jk_session& s_;
     std::string fn_;
     bool null_ = false;
     int fd_ = -1; gzFile gz_ = nullptr;
     uint64_t at_ = 0;            // next byte of the file
     uint64_t plain_ = 0;         // FASTQ bytes taken so far
-    DevBuf comp_;
+    HostPipe* pipe_ = nullptr;   // the pipe this file's pieces went through
+    DevBuf comp_[2];             // compressed pieces on their way to the host, in rotation
     BgzfScratch bgzf_scratch_;   // kept from piece to piece
+    hipStream_t zstream_ = nullptr;
+    uint64_t n_pieces_ = 0;
+    std::thread copier_;
+    std::mutex cm_; std::condition_variable ccv_;
+    std::deque<CopyTask> cq_;
+    bool cbusy_[2] = {false, false}, cstop_ = false;
+    std::string cerr_;
 };
 
 static const size_t PIPE_PIECE = BGZF_IN * 512;      // 33.4 MB pieces, a whole number of BGZF blocks

@@ -668,13 +668,30 @@ bgzf_deflate_lz_kernel(const uint8_t* __restrict__ src, uint64_t n_total, uint8_
             carry = x >> 24;
             m1 |= (uint64_t)e1 << (4 * w);
             const uint32_t nl4 = (uint32_t)(nlm >> (4 * w)) & 0xfu;
-            if (nl4 == 0) {                                               // one line, one distance
-                if (D && g0 + 4u * w >= D) {
-                    const uint32_t a = g0 + 4u * w - D;
-                    const uint32_t lo = inw[a >> 2], hi = inw[(a >> 2) + 1u];
-                    const uint32_t sw = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (a & 3u)));
-                    mR |= (uint64_t)zero_bytes(x ^ sw) << (4 * w);
+            // the bytes of the word up to and including a newline belong to line k (distance D), those behind it to line
+            // k + 1 (distance D2): both comparisons are made for the whole word and merged by position -- among the 64
+            // lanes of a wave some word always holds a newline, so a per-byte path for that case ran for every word
+            auto eq_word = [&](uint32_t dist) -> uint32_t {
+                if (!dist || g0 + 4u * w < dist) {
+                    // (the first bytes of the block may lie closer to its start than the distance: byte by byte)
+                    uint32_t e = 0;
+                    if (dist) for (uint32_t b = 0; b < 4; b++) { const uint32_t j = 4 * w + b; if (g0 + j >= dist && inb[g0 + j - dist] == ((x >> (8 * b)) & 0xffu)) e |= 1u << b; }
+                    return e;
                 }
+                const uint32_t a = g0 + 4u * w - dist;
+                const uint32_t lo = inw[a >> 2], hi = inw[(a >> 2) + 1u];
+                return zero_bytes(x ^ (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (a & 3u))));
+            };
+            if ((nl4 & (nl4 - 1u)) == 0) {                                // at most one newline in the word
+                uint32_t e = eq_word(D);
+                if (nl4) {
+                    k++;
+                    const uint32_t D2 = rec_dist(k);
+                    const uint32_t first = nl4 | (nl4 - 1u);              // bytes up to and including the newline
+                    e = (e & first) | (eq_word(D2) & ~first);
+                    D = D2;
+                }
+                mR |= (uint64_t)e << (4 * w);
             } else {
                 for (uint32_t b = 0; b < 4; b++) {
                     const uint32_t j = 4 * w + b;
