@@ -213,9 +213,32 @@ def fasta_case(ja, O, rng, case, tmp):
 def bgzf_case(ja, O, rng, case):
     import gzip
     n = int(rng.choice([0, 1, 63, 64, 65, 0xff00 - 1, 0xff00, 0xff00 + 1, rng.integers(1, 400000)]))
-    style = rng.choice(["fastq", "uniform", "skewed", "runs", "binary"])
+    style = rng.choice(["fastq", "uniform", "skewed", "runs", "binary", "records", "records", "lines"])
     if style == "fastq":
         data = bytes(np.frombuffer(b"ACGTN\n@+IIIIFFF#", dtype=np.uint8)[rng.integers(0, 16, size=n)])
+    elif style == "records":
+        # FASTQ-shaped: records of (nearly) equal length whose lines repeat the previous record's in the same columns -- what
+        # the device matcher looks for: id prefixes and suffixes, "+", low-entropy qualities, whole duplicated records,
+        # records a byte longer or shorter than their predecessor (the distance changes at a line start), empty lines
+        L = int(rng.choice([1, 4, 30, 75, 150, 300, 2000]))
+        out, prev = [], None
+        alpha_q = np.frombuffer(b"CCCGGGGJJ=8", dtype=np.uint8)
+        while sum(len(r) for r in out) < n:
+            if prev is not None and rng.random() < 0.1:
+                rec = prev
+            else:
+                ll = max(L + int(rng.choice([0, 0, 0, 1, -1])), 0)
+                hdr = b"@REF-chrom%d-%d-%s/%d" % (int(rng.integers(0, 3)), int(rng.integers(0, 10 ** int(rng.integers(1, 9)))), b"FR"[int(rng.integers(0, 2)):][:1], int(rng.integers(1, 3)))
+                seq = np.frombuffer(b"TCAG", dtype=np.uint8)[rng.integers(0, 4, size=ll)].tobytes()
+                qual = alpha_q[rng.integers(0, alpha_q.size, size=ll)].tobytes()
+                rec = hdr + b"\n" + seq + b"\n+\n" + qual + b"\n"
+            out.append(rec); prev = rec
+        data = b"".join(out)[:n]
+    elif style == "lines":
+        out = []
+        while sum(len(r) for r in out) < n:
+            out.append(np.frombuffer(b"ab", dtype=np.uint8)[rng.integers(0, 2, size=int(rng.integers(0, 200)))].tobytes() + b"\n")
+        data = b"".join(out)[:n]
     elif style == "uniform":
         data = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
     elif style == "skewed":
