@@ -289,7 +289,7 @@ def dist_setup(a):
     return rank, local_rank, world, use_dist
 
 
-def timed_steps(a, sess, use_dist):
+def timed_steps(a, sess, use_dist, pipelined=False):
     """W warm-up passes, then K passes between barrier + synchronize on both sides; MAX over ranks of the elapsed time."""
     import torch
     import torch.distributed as dist
@@ -306,13 +306,29 @@ def timed_steps(a, sess, use_dist):
     gen_ms = all_ms = 0.0
     global STEP_MS
     STEP_MS = []
-    for _ in range(a.steps):
+    if pipelined:
+        # K steps, each a whole job (every lane's reads generated and assembled into the FASTQ image in HBM), queued so
+        # that two are in flight: the next step's first generator launch runs beside this step's last compaction -- the
+        # way job follows job in a caller with more than one (sep_files haplotypes, call after call).  The per-launch
+        # kernel time comes from the last step's HIP events.
         t1 = time.perf_counter()
-        sess.generate()                      # blocks until the step's stream work is done
+        for k in range(a.steps):
+            sess.generate_async()
+            if k >= 1:
+                sess.wait()
+                t2 = time.perf_counter(); STEP_MS.append((t2 - t1) * 1e3); t1 = t2
+        sess.wait()
         STEP_MS.append((time.perf_counter() - t1) * 1e3)
-        tm = sess.timing_ms()                # HIP events on the stream the kernels run on
-        gen_ms += tm["generate_kernel"]
-        all_ms += tm["total"]
+        tm = sess.timing_ms()
+        gen_ms, all_ms = tm["generate_kernel"] * a.steps, tm["total"] * a.steps
+    else:
+        for _ in range(a.steps):
+            t1 = time.perf_counter()
+            sess.generate()                      # blocks until the step's stream work is done
+            STEP_MS.append((time.perf_counter() - t1) * 1e3)
+            tm = sess.timing_ms()                # HIP events on the stream the kernels run on
+            gen_ms += tm["generate_kernel"]
+            all_ms += tm["total"]
     sync()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=XDEV)
@@ -452,7 +468,7 @@ def hap_main(a):
                                                       lane_begin=lo, lane_end=hi, seed_offset_words=off, _session=True),
                       lanes, n_reads // 2, 8 + 16 * n_haps, device=XDEV if use_dist else None)
     open_s = time.perf_counter() - t0
-    elapsed, gen_ms, all_ms = timed_steps(a, sess, use_dist)
+    elapsed, gen_ms, all_ms = timed_steps(a, sess, use_dist, pipelined=not a.sync_steps)
     sizes, reads = sess.sizes()
     offsets, (total_reads, total_bytes) = exchange_counts(reads, sizes, device=XDEV)
     if rank == 0:
@@ -488,6 +504,7 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = choose for about 15 s of CPU work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the D2H-inclusive and copy-bandwidth measurements")
+    ap.add_argument("--sync-steps", action="store_true", help="Illumina lines: one step at a time (host sync after every step) instead of two in flight")
     ap.add_argument("--workload", choices=["illumina", "hap", "pacbio", "bgzf", "create_genome", "read_fasta"], default="illumina",
                     help="illumina = the headline metric (BASELINE configs[1]); hap = configs[3]'s share of one GPU; pacbio = "
                          "configs[4]; bgzf = the device-side compressed sink on the headline workload's FASTQ")
@@ -511,13 +528,23 @@ def main():
 
     read_length = 150
     genome = ja.synthetic_genome([int(a.genome_mbp * 1e6)], seed=2)
+    if not a.sync_steps:
+        # steps two in flight: every launch, the first of a step included, leaves an eighth of the CUs to the compaction of
+        # the launch before it (the previous step's last one): four launches of 224 x 1024 lanes
+        os.environ.setdefault("JK_FIRST_LAUNCH_FULL", "0")
+        if a.lanes == DEFAULT_LANES:
+            a.lanes = 4 * 224 * 1024
     total_lanes = a.lanes * world
     n_reads = 2 * a.pairs * world
     words = ja.seed_words(12345, 16 * total_lanes)
     sess = open_shard(lambda lo, hi, off: ja.illumina(genome, None, n_reads, read_length, True, n_threads=total_lanes, seed_words=words,
                                                       device=local_rank, lane_begin=lo, lane_end=hi, seed_offset_words=off, _session=True),
                       total_lanes, n_reads // 2, 8, device=XDEV if use_dist else None)
-    elapsed, gen_ms, all_ms = timed_steps(a, sess, use_dist)
+    elapsed, gen_ms, all_ms = timed_steps(a, sess, use_dist, pipelined=not a.sync_steps)
+    spread = step_spread()
+    sync_elapsed = None
+    if not a.sync_steps and not a.no_extras:        # the same K steps one at a time (host sync after every step), for the record
+        sync_elapsed, _, _ = timed_steps(a, sess, use_dist)
 
     sizes, reads_made = sess.sizes()
     pairs_rank = reads_made // 2
@@ -557,8 +584,11 @@ def main():
                                  "traffic = (2*FETCH_SIZE + WRITE_SIZE) of the committed rocprofv3 --pmc passes "
                                  "(profiles/), null when they were taken at another launch size"
                                  % (1206.0 * pairs_rank / n_launch / kern_s)},
-            "device_ms_per_step": round(all_ms / a.steps, 3), "step_ms": step_spread(),
+            "device_ms_per_step": round(all_ms / a.steps, 3), "step_ms": spread,
+            "steps_mode": "one at a time" if a.sync_steps else "pipelined: two steps in flight, the next step's first launch beside this step's last compaction",
         }
+        if sync_elapsed is not None:
+            out["value_one_step_at_a_time"] = round(total_pairs * a.steps / sync_elapsed / 1e6, 3)
         # Since round 2 a launch takes 7/8 of the CUs and the compaction of the launch before runs on the rest, beside
         # it: per launch the generator kernel is slower than on the whole chip (roofline.kernel_ms), the step is faster.
         # The same algorithmic bytes over the whole step:

@@ -236,6 +236,13 @@ int jk_pacbio_hap_open(const jk_hap_set* haps, const jk_pacbio_args* args, jk_se
 /* Run every batch of this session's lanes: generator kernel, per-lane byte-count scan, pool
  * compaction into the lane-major FASTQ images.  May be called repeatedly (same output each time). */
 int jk_session_generate(jk_session* s);
+/* The same in two halves: _generate_async queues one pass over the session's lanes and returns, _wait completes the
+   oldest queued pass (sizes, timing and the FASTQ image are then those of that pass).  Up to two passes may be queued:
+   the generator launches of the second run beside the last compaction of the first, which is what a caller with job
+   after job to run (the per-haplotype loop of /root/reference/src/hts.h:512-552, repeated illumina() calls) wants.
+   Illumina sessions without stream_output. */
+int jk_session_generate_async(jk_session* s);
+int jk_session_wait(jk_session* s);
 /* Streaming sessions (args.stream_output): run every batch and write <out_prefix>_R<e+1>.fq[.gz] while generating.
  * out_prefix "" (or NULL) = null sink: the FASTQ (or its BGZF form when compress > 0) is brought to host memory and
  * dropped, which is what bench.py times as the D2H-inclusive rate.  Blocks until the files are closed; another thread

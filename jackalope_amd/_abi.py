@@ -112,7 +112,7 @@ EXPORTS = [
     "jk_last_error", "jk_version", "jk_device_count", "jk_device_arena_trim", "jk_device_arena_stats", "jk_illumina_ref", "jk_illumina_hap", "jk_pacbio_ref", "jk_pacbio_hap",
     "jk_illumina_ref_job", "jk_illumina_hap_job", "jk_pacbio_ref_job", "jk_pacbio_hap_job", "jk_job_n_files", "jk_job_plan_next", "jk_job_run",
     "jk_job_progress", "jk_job_seed_words_used", "jk_job_free",
-    "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_pacbio_ref_open", "jk_pacbio_hap_open", "jk_session_generate", "jk_session_run", "jk_session_progress", "jk_session_sizes",
+    "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_pacbio_ref_open", "jk_pacbio_hap_open", "jk_session_generate", "jk_session_generate_async", "jk_session_wait", "jk_session_run", "jk_session_progress", "jk_session_sizes",
     "jk_session_device_ptr", "jk_session_fetch", "jk_session_fetch_range", "jk_session_write", "jk_session_write_shard",
     "jk_session_shard_seed_words", "jk_session_timing",
     "jk_session_seed_words_used", "jk_session_retries", "jk_session_batches", "jk_session_lane_bytes", "jk_session_close",
@@ -173,6 +173,8 @@ def lib():
     L.jk_job_free.argtypes = [C.c_void_p]
     L.jk_job_free.restype = None
     L.jk_session_generate.argtypes = [C.c_void_p]
+    L.jk_session_generate_async.argtypes = [C.c_void_p]
+    L.jk_session_wait.argtypes = [C.c_void_p]
     L.jk_session_run.argtypes = [C.c_void_p]
     L.jk_session_progress.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.jk_session_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]

@@ -52,13 +52,13 @@ struct StreamCtx {
                     b = q.front(); q.pop_front();
                 }
                 JK_HIP(hipEventSynchronize(s.cp_done[b]));
-                uint32_t kerr = 0;
-                JK_HIP(hipMemcpyAsync(&kerr, s.d_err.p, 4, hipMemcpyDeviceToHost, pipe.stream()));
+                uint32_t kerr2[2] = {0, 0};                  // (the error words of both step slots: a run uses one of them)
+                JK_HIP(hipMemcpyAsync(kerr2, s.d_err.p, 8, hipMemcpyDeviceToHost, pipe.stream()));
                 uint64_t base[2][2] = {{0, 0}, {0, 0}};
                 for (uint32_t e = 0; e < s.n_ends; e++)
                     JK_HIP(hipMemcpyAsync(base[e], s.d_base[e].as<uint64_t>() + b, 16, hipMemcpyDeviceToHost, pipe.stream()));
                 JK_HIP(hipStreamSynchronize(pipe.stream()));
-                if (kerr) { fail(JK_ERR_DEVICE, "kernel error"); return; }      // (the caller reads the bits and words the message)
+                if (kerr2[0] | kerr2[1]) { fail(JK_ERR_DEVICE, "kernel error"); return; }      // (the caller reads the bits and words the message)
                 const int slot = b & 1;
                 for (uint32_t e = 0; e < s.n_ends; e++)
                     files[e]->add(pipe, s.d_img[slot][e].as<uint8_t>(), base[e][1] - base[e][0]);
@@ -73,14 +73,21 @@ struct StreamCtx {
 
 // One pass over all batches of the session.  `sc` == nullptr: the images of all batches end up side by side in the
 // resident image (d_out).  Otherwise every batch's image goes to one of two per-batch buffers and on to the sink.
-static void launch_batches(jk_session& s, StreamCtx* sc) {
+static void complete_step(jk_session& s, StreamCtx* sc, int slot, bool stopped, size_t ev);
+
+// `pipelined`: return once the step is queued (jk_session_generate_async); jk_session_wait completes it.  Two steps may
+// be in flight: the generator launches of step k + 1 then run beside the last compaction of step k, whose pool set they do
+// not use -- the un-overlapped tail of a step (about a tenth of the headline step) is hidden behind the next step's head.
+static void launch_batches(jk_session& s, StreamCtx* sc, bool pipelined = false) {
     JK_HIP(hipSetDevice(s.device));
-    JK_HIP(hipMemsetAsync(s.d_err.p, 0, 4, s.stream));
-    for (uint32_t e = 0; e < s.n_ends; e++) JK_HIP(hipMemsetAsync(s.d_base[e].p, 0, 8, s.stream));
+    const int step_slot = s.next_slot;
+    uint32_t* const err_ptr = s.d_err.as<uint32_t>() + step_slot;
+    JK_HIP(hipMemsetAsync(err_ptr, 0, 4, s.stream));
+    if (s.inflight == 0) for (uint32_t e = 0; e < s.n_ends; e++) JK_HIP(hipMemsetAsync(s.d_base[e].p, 0, 8, s.stream));      // (entry 0 stays 0)
     s.progress_done.store(0);
     size_t ev = 0;
     JK_HIP(hipEventRecord(s.events[ev++], s.stream));
-    JK_HIP(hipStreamWaitEvent(s.cp_stream, s.events[0], 0));
+    if (s.inflight == 0) JK_HIP(hipStreamWaitEvent(s.cp_stream, s.events[0], 0));
     bool stopped = false;
     for (size_t b = 0; b < s.batches.size(); b++) {
         if (s.abort_flag && *s.abort_flag) { stopped = true; break; }
@@ -100,6 +107,7 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
             // b + 1 runs beside the emit kernel of launch b, each with its own set of records / masks / counters
             const int set = (int)(b & 1);
             PacbioKernelParams Q = s.kpb;
+            Q.err = err_ptr;
             Q.n_lanes = B.n_lanes;
             Q.seeds = s.d_seeds.as<uint32_t>() + B.lane0 * 8;
             Q.lane_reads = s.d_lane_reads.as<uint64_t>() + B.lane0;
@@ -149,7 +157,7 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
             E.seeds = Q.seeds; E.lane_off = lo;
             E.masks = Q.masks; E.stale = Q.stale; E.jump = Q.jump;
             E.out = out_img[0]; E.out_base = out_base[0]; E.out_cap = out_cap;
-            E.err = s.d_err.as<uint32_t>();
+            E.err = err_ptr;
             if (B.n_reads) {
                 if (Q.hap_seg) hipLaunchKernelGGL((pb_emit_kernel<true>), dim3((uint32_t)B.n_reads), dim3(64), 0, s.cp_stream, E);
                 else hipLaunchKernelGGL((pb_emit_kernel<false>), dim3((uint32_t)B.n_reads), dim3(64), 0, s.cp_stream, E);
@@ -160,6 +168,7 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
             continue;
         }
         IlluminaKernelParams P = s.kp;
+        P.err = err_ptr;
         P.n_lanes = B.n_lanes;
         P.seeds = s.d_seeds.as<uint32_t>() + B.lane0 * 8;
         P.lane_reads = s.d_lane_reads.as<uint64_t>() + B.lane0;
@@ -179,8 +188,15 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
         if (s.two_gen_streams && b == 1) JK_HIP(hipStreamWaitEvent(s.stream2, s.events[0], 0));
         const uint32_t block = JK_ILL_BLOCK;
         const uint32_t grid = (B.n_lanes + block - 1) / block;
-        // the pool set is free again once the compaction of batch b-2 has read it
+        // the pool set is free again once the compaction of batch b-2 has read it -- of this step, or (a step queued
+        // behind another) the last batch of the step before that used the set: its event still holds that record
         if (b >= ns) JK_HIP(hipStreamWaitEvent(gs, s.cp_done[b - ns], 0));
+        else if (s.inflight > 0) {
+            const size_t nb = s.batches.size();
+            size_t last = nb;                            // largest b' < nb with b' % ns == pp
+            for (size_t k = nb; k-- > 0;) if ((int)(k % ns) == pp) { last = k; break; }
+            if (last < nb) JK_HIP(hipStreamWaitEvent(gs, s.cp_done[last], 0));
+        }
         JK_HIP(hipEventRecord(s.events[ev++], gs));
 #define JK_LAUNCH(LDS, NE, HAP, SEG, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP, SEG>), dim3(grid), dim3(block), SH, gs, P)
         const bool seg = s.hap && !s.hap_materialised;       // bases through the mutation tables (else: plain sequences)
@@ -219,29 +235,42 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
         (void)hipStreamSynchronize(s.stream); (void)hipStreamSynchronize(s.cp_stream);
         if (s.stream2) (void)hipStreamSynchronize(s.stream2);
         if (sc) sc->close();
+        s.inflight = 0;
         if (s.abort_flag && *s.abort_flag) throw Error(JK_ERR_ABORTED, "aborted");
     }
-    if (!stopped && !s.batches.empty()) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[s.batches.size() - 1], 0));
-    if (!s.d_result.p) s.d_result.alloc(32);
-    JK_HIP(hipMemsetAsync(s.d_result.p, 0, 32, s.stream));
-    hipLaunchKernelGGL(finish_kernel, dim3(64), dim3(256), 0, s.stream, s.d_lane_made.as<uint64_t>(), (uint64_t)s.n_shard, s.d_err.as<uint32_t>(),
+    // the step's summary, behind its last compaction: {error bits, bytes per end, reads} in the step's result slot
+    if (!s.d_result.p) { s.d_result.alloc(64); }
+    uint64_t* const res = s.d_result.as<uint64_t>() + 4 * step_slot;
+    JK_HIP(hipMemsetAsync(res, 0, 32, s.cp_stream));
+    hipLaunchKernelGGL(finish_kernel, dim3(64), dim3(256), 0, s.cp_stream, s.d_lane_made.as<uint64_t>(), (uint64_t)s.n_shard, err_ptr,
                        s.d_base[0].as<uint64_t>() + s.batches.size(),
-                       s.n_ends > 1 ? s.d_base[1].as<uint64_t>() + s.batches.size() : (const uint64_t*)nullptr, s.d_result.as<uint64_t>());
+                       s.n_ends > 1 ? s.d_base[1].as<uint64_t>() + s.batches.size() : (const uint64_t*)nullptr, res);
     JK_HIP(hipGetLastError());
-    if (!stopped) JK_HIP(hipEventRecord(s.events[ev++], s.stream));
-    JK_HIP(hipStreamSynchronize(s.stream));
-    JK_HIP(hipStreamSynchronize(s.cp_stream));
+    if (!stopped) JK_HIP(hipEventRecord(s.events[ev++], s.cp_stream));
+    JK_HIP(hipEventRecord(s.step_end[step_slot], s.cp_stream));
+    s.inflight++;
+    s.next_slot ^= 1;
+    s.pending_ev[step_slot] = ev;
+    if (pipelined && !stopped && !sc) return;
+    complete_step(s, sc, step_slot, stopped, ev);
+}
+
+// wait for the step in `slot` and take its results
+static void complete_step(jk_session& s, StreamCtx* sc, int slot, bool stopped, size_t ev) {
+    JK_HIP(hipEventSynchronize(s.step_end[slot]));
+    if (s.inflight == 1) { JK_HIP(hipStreamSynchronize(s.stream)); JK_HIP(hipStreamSynchronize(s.cp_stream)); }
+    s.inflight--;
     if (sc) sc->close();               // the sink has taken every batch it was given (or failed)
 
     uint64_t result[4] = {0, 0, 0, 0};
-    JK_HIP(hipMemcpy(result, s.d_result.p, sizeof(result), hipMemcpyDeviceToHost));
+    JK_HIP(hipMemcpy(result, s.d_result.as<uint64_t>() + 4 * slot, sizeof(result), hipMemcpyDeviceToHost));
     const uint32_t err = (uint32_t)result[0];
     if (err & JK_KERR_GAMMA_MATH) throw Error(JK_ERR_UNSUPPORTED, "a fragment-length draw with frag_len_shape < 1 needed pow() beyond the range implemented on the GPU (|log(u) / shape| >= 512)");
     if (err & JK_KERR_PB_MATH) throw Error(JK_ERR_UNSUPPORTED, "a PacBio parameter led to an exp/pow argument outside the range implemented on the GPU");
     if (err & JK_KERR_PB_TOO_LONG) throw Error(JK_ERR_UNSUPPORTED, "a read was longer than 2^30 bases or needed more than twice its length in reference positions (deletion probability too high for the GPU path)");
     if (err & JK_KERR_PB_SPACE) throw Error(JK_ERR_UNSUPPORTED, "a read position lies outside the reference's read buffer (undefined there: a read as long as its chromosome or a clipped duplicate with no earlier, longer read on its thread) or needs more chromosome than there is");
-    // PacBio images are sized for the expected read length (the pools' worst case would not fit): a length model whose
-    // realised mean is above that (e.g. min_read_length cutting off most of the log-normal) gets a larger image
+    // PacBio images are sized for the expected read length: a length model whose realised mean is above that (e.g.
+    // min_read_length cutting off most of the log-normal) gets a larger image
     if ((err & JK_KERR_IMAGE_FULL) && s.pacbio && s.replan && !std::getenv("JK_PB_NO_IMAGE_RETRY")) throw Error(JK_ERR_RETRY_IMAGE, "image full");
     if (err & JK_KERR_IMAGE_FULL) throw Error(JK_ERR_DEVICE, "the FASTQ image of this run does not fit in device memory next to its pools: use more GPUs (lane shards) or fewer reads per call");
     if ((err & JK_KERR_POOL_OVERFLOW) && s.pacbio) throw Error(JK_ERR_RETRY, "pool overflow");
@@ -251,32 +280,56 @@ static void launch_batches(jk_session& s, StreamCtx* sc) {
     if (stopped) throw Error(JK_ERR_DEVICE, "the run stopped early");
     for (uint32_t e = 0; e < s.n_ends; e++) s.bytes[e] = result[1 + e];
     s.reads_made = result[3];
-    float t = 0;
-    double gen = 0, rest = 0;
-    {   // time with a generator launch running: the union of the launches' spans (PacBio launches overlap)
-        std::vector<std::pair<float, float>> span(s.batches.size());
-        for (size_t b = 0; b < s.batches.size(); b++) {
-            JK_HIP(hipEventElapsedTime(&span[b].first, s.events[0], s.events[1 + 2 * b]));
-            JK_HIP(hipEventElapsedTime(&span[b].second, s.events[0], s.events[2 + 2 * b]));
+    if (s.inflight == 0) {
+        // (the timing events are the session's, not the step's: with another step queued behind this one they already hold
+        //  that step's records -- the times of a pipelined run are those of its last step)
+        float t = 0;
+        double gen = 0, rest = 0;
+        {   // time with a generator launch running: the union of the launches' spans
+            std::vector<std::pair<float, float>> span(s.batches.size());
+            for (size_t b = 0; b < s.batches.size(); b++) {
+                JK_HIP(hipEventElapsedTime(&span[b].first, s.events[0], s.events[1 + 2 * b]));
+                JK_HIP(hipEventElapsedTime(&span[b].second, s.events[0], s.events[2 + 2 * b]));
+            }
+            std::sort(span.begin(), span.end());
+            float hi = -1.0f;
+            for (const auto& sp : span) {
+                const float a = std::max(sp.first, hi);
+                if (sp.second > a) gen += sp.second - a;
+                hi = std::max(hi, sp.second);
+            }
         }
-        std::sort(span.begin(), span.end());
-        float hi = -1.0f;
-        for (const auto& sp : span) {
-            const float a = std::max(sp.first, hi);
-            if (sp.second > a) gen += sp.second - a;
-            hi = std::max(hi, sp.second);
-        }
+        JK_HIP(hipEventElapsedTime(&t, s.events[0], s.events[ev - 1]));
+        rest = t - gen;
+        s.ms[0] = gen; s.ms[1] = rest; s.ms[2] = t;
     }
-    JK_HIP(hipEventElapsedTime(&t, s.events[0], s.events[ev - 1]));
-    rest = t - gen;
-    s.ms[0] = gen; s.ms[1] = rest; s.ms[2] = t;
     s.progress_done.store(s.progress_total);
 }
 
 // generate(): all batches into the resident image
+static void drain_steps(jk_session& s) {      // complete whatever is queued (oldest first)
+    while (s.inflight > 0) {
+        const int slot = s.inflight == 2 ? s.next_slot : (s.next_slot ^ 1);
+        complete_step(s, nullptr, slot, false, s.pending_ev[slot]);
+    }
+}
 static void launch_generate(jk_session& s) {
     if (s.streaming) throw Error(JK_ERR_ARG, "this session streams its output (stream_output): use jk_session_run");
+    drain_steps(s);
     launch_batches(s, nullptr);
+    s.generated = true;
+}
+// generate_async(): queue one more pass over all batches (at most two in flight); wait(): complete the oldest
+static void launch_generate_async(jk_session& s) {
+    if (s.streaming) throw Error(JK_ERR_ARG, "this session streams its output (stream_output): use jk_session_run");
+    if (s.pacbio) throw Error(JK_ERR_UNSUPPORTED, "pipelined steps are implemented for the Illumina sessions");
+    if (s.inflight >= 2) throw Error(JK_ERR_ARG, "two steps are in flight already: jk_session_wait first");
+    launch_batches(s, nullptr, true);
+}
+static void launch_wait(jk_session& s) {
+    if (s.inflight == 0) throw Error(JK_ERR_ARG, "no step is in flight");
+    const int slot = s.inflight == 2 ? s.next_slot : (s.next_slot ^ 1);
+    complete_step(s, nullptr, slot, false, s.pending_ev[slot]);
     s.generated = true;
 }
 

@@ -155,6 +155,13 @@ int jk_session_generate(jk_session* s) {
     return guarded([&] { if (!s) throw Error(JK_ERR_ARG, "NULL session"); generate_with_retry(*s); });
 }
 
+int jk_session_generate_async(jk_session* s) {
+    return guarded([&] { if (!s) throw Error(JK_ERR_ARG, "NULL session"); launch_generate_async(*s); });
+}
+int jk_session_wait(jk_session* s) {
+    return guarded([&] { if (!s) throw Error(JK_ERR_ARG, "NULL session"); launch_wait(*s); });
+}
+
 int jk_session_sizes(const jk_session* s, uint64_t bytes[2], uint64_t* reads, uint32_t* n_ends) {
     return guarded([&] {
         if (!s || !(s->generated || s->streamed)) throw Error(JK_ERR_ARG, "session has not generated yet");

@@ -78,11 +78,16 @@ struct jk_session {
     const volatile int32_t* abort_flag = nullptr;
     std::vector<hipEvent_t> events;       // [0] start, [1+2b] / [2+2b] around generator b, last = end
     std::vector<hipEvent_t> gen_done, cp_done;   // per batch, for the two-stream hand-off
+    // steps (passes over all batches) in flight: at most two (jk_session_generate_async / jk_session_wait)
+    int inflight = 0, next_slot = 0;
+    hipEvent_t step_end[2] = {nullptr, nullptr};
+    size_t pending_ev[2] = {0, 0};
 
     ~jk_session() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         for (hipEvent_t e : gen_done) (void)hipEventDestroy(e);
         for (hipEvent_t e : cp_done) (void)hipEventDestroy(e);
+        for (hipEvent_t e : step_end) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
         if (cp_stream) (void)hipStreamDestroy(cp_stream);
         if (stream2) (void)hipStreamDestroy(stream2);

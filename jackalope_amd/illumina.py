@@ -132,6 +132,16 @@ class IlluminaSession:
         _abi.check(_abi.lib().jk_session_generate(self._h))
         return self
 
+    def generate_async(self):
+        """Queue one pass (at most two may be queued); wait() completes the oldest.  Consecutive passes overlap: the next
+        one's generator launches run beside this one's last compaction."""
+        _abi.check(_abi.lib().jk_session_generate_async(self._h))
+        return self
+
+    def wait(self):
+        _abi.check(_abi.lib().jk_session_wait(self._h))
+        return self
+
     def run(self):
         """Streaming sessions (stream_output=True): generate and write the files (or the null sink) in one pass."""
         _abi.check(_abi.lib().jk_session_run(self._h))
