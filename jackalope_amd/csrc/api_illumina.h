@@ -467,7 +467,8 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
     size_t max_hdr = 0;
     const std::string gname = g.name ? g.name : "REF";
     for (uint64_t i = 0; i < g.n_chroms; i++) {
-        min_chrom = std::min<uint64_t>(min_chrom, g.chrom_lens[i]);
+        // (an empty chromosome has probability 0 in reads_per_group, src/hts.h:78: it gets no reads and does not count here)
+        if (g.chrom_lens[i]) min_chrom = std::min<uint64_t>(min_chrom, g.chrom_lens[i]);
         max_chrom = std::max<uint64_t>(max_chrom, g.chrom_lens[i]);
         max_hdr = std::max(max_hdr, 3 + gname.size() + std::strlen(g.chrom_names ? g.chrom_names[i] : ""));
     }
@@ -485,8 +486,14 @@ static void open_illumina_ref(jk_session& s, const jk_ref_genome& g, const jk_il
         s.d_hdr_off.upload(hoff);
     }
     const uint64_t frag_lb = std::min<uint64_t>(a.frag_len_min <= a.frag_len_max ? a.frag_len_min : a.frag_len_max, min_chrom);
-    if (frag_lb < std::max<uint64_t>(barcode.size(), 1))
-        throw Error(JK_ERR_UNSUPPORTED, "fragments shorter than the barcode (or empty) are not implemented on the GPU path");
+    if (max_chrom == 0) throw Error(JK_ERR_ARG, "the genome holds no bases");
+    // a fragment shorter than the barcode: the reference's `read_chrom_spaces[r] -= barcode.size()` wraps below zero and
+    // `read[i] = barcode[i]` writes past the string (src/hts_illumina.cpp:177-182, :391) -- undefined there, refused here
+    if (frag_lb == 0)            // (R's illumina() demands frag_len_min >= 1, R/hts_illumina.R:327-331; the reference would write records without bases)
+        throw Error(JK_ERR_UNSUPPORTED, "frag_len_min = 0 (empty fragments) is not implemented on the GPU path");
+    if (frag_lb < barcode.size())
+        throw Error(JK_ERR_UNSUPPORTED, "fragments can be shorter than the barcode (frag_len_min or a chromosome of " + std::to_string(frag_lb) +
+                    " bases against a barcode of " + std::to_string(barcode.size()) + "): undefined in the reference, refused here");
 
     // ---- lanes, quotas, seeds: same order of seed consumption as src/hts.h:334-353 (mt_seeds, then per lane
     // IlluminaOneGenome::add_n_reads, src/hts_illumina.h:410-418); see jk_plan.h
@@ -521,7 +528,7 @@ static void upload_hap_tables(jk_session& s, const jk_hap_set& hs, uint64_t& min
     const uint64_t* new_pos = hs.new_pos;
     cell_size.assign(hs.chrom_size, hs.chrom_size + n_cells);
     for (uint64_t k = 0; k < n_cells; k++) {
-        min_chrom = std::min(min_chrom, cell_size[k]);
+        if (cell_size[k]) min_chrom = std::min(min_chrom, cell_size[k]);      // (an empty cell gets no reads, as an empty chromosome)
         max_chrom = std::max(max_chrom, cell_size[k]);
     }
     parallel_for(n_cells, 1, [&](size_t ka, size_t kb, unsigned) {
@@ -665,8 +672,11 @@ static void open_illumina_hap(jk_session& s, const jk_hap_set& hs, const jk_illu
         s.d_hdr_off.upload(hoff);
     }
     const uint64_t frag_lb = std::min<uint64_t>(a.frag_len_min <= a.frag_len_max ? a.frag_len_min : a.frag_len_max, min_chrom);
-    if (frag_lb < std::max<uint64_t>(max_bc, 1))
-        throw Error(JK_ERR_UNSUPPORTED, "fragments shorter than the barcode (or empty) are not implemented on the GPU path");
+    if (max_chrom == 0) throw Error(JK_ERR_ARG, "the haplotypes hold no bases");
+    if (frag_lb == 0) throw Error(JK_ERR_UNSUPPORTED, "frag_len_min = 0 (empty fragments) is not implemented on the GPU path");
+    if (frag_lb < max_bc)         // (undefined in the reference: see open_illumina_ref)
+        throw Error(JK_ERR_UNSUPPORTED, "fragments can be shorter than the barcode (frag_len_min or a chromosome of " + std::to_string(frag_lb) +
+                    " bases against a barcode of " + std::to_string(max_bc) + "): undefined in the reference, refused here");
 
     // ---- lanes, quotas, seeds.  IlluminaHaplotypes::add_n_reads (src/hts_illumina.h:620-644) per lane:
     // reads_per_group over haplotypes, then per haplotype reads_per_group over its chromosomes, then

@@ -266,6 +266,7 @@ static void complete_step(jk_session& s, StreamCtx* sc, int slot, bool stopped, 
     JK_HIP(hipMemcpy(result, s.d_result.as<uint64_t>() + 4 * slot, sizeof(result), hipMemcpyDeviceToHost));
     const uint32_t err = (uint32_t)result[0];
     if (err & JK_KERR_GAMMA_MATH) throw Error(JK_ERR_UNSUPPORTED, "a fragment-length draw with frag_len_shape < 1 needed pow() beyond the range implemented on the GPU (|log(u) / shape| >= 512)");
+    if (err & JK_KERR_EMPTY_CHROM) throw Error(JK_ERR_UNSUPPORTED, "a lane was given reads for an empty chromosome (the reference hands reads_per_group's remainder to the last chromosome whatever its length and writes records without bases)");
     if (err & JK_KERR_PB_MATH) throw Error(JK_ERR_UNSUPPORTED, "a PacBio parameter led to an exp/pow argument outside the range implemented on the GPU");
     if (err & JK_KERR_PB_TOO_LONG) throw Error(JK_ERR_UNSUPPORTED, "a read was longer than 2^30 bases or needed more than twice its length in reference positions (deletion probability too high for the GPU path)");
     if (err & JK_KERR_PB_SPACE) throw Error(JK_ERR_UNSUPPORTED, "a read position lies outside the reference's read buffer (undefined there: a read as long as its chromosome or a clipped duplicate with no earlier, longer read on its thread) or needs more chromosome than there is");

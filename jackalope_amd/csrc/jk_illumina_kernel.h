@@ -41,6 +41,7 @@ enum : uint32_t {
     JK_KERR_IMAGE_FULL = 64u,          // the compacted FASTQ image would not fit the buffer allocated for it (PacBio: see plan_pools_common)
     JK_KERR_TOO_MANY_DELETIONS = 1u,   // a read end needed more source positions than the event bitmaps hold
     JK_KERR_POOL_OVERFLOW = 2u,        // internal: a lane wrote past its pool region
+    JK_KERR_EMPTY_CHROM = 256u,        // a lane holds reads for an empty chromosome (reads_per_group's last group takes the remainder whatever its probability)
     JK_KERR_GAMMA_MATH = 128u,         // gamma shape < 1: pow(u, 1/shape) left the transcribed main path of glibc's pow (|y log u| >= 512)
 };
 
@@ -499,6 +500,7 @@ illumina_kernel(IlluminaKernelParams P) {
                 }
             }
             const uint64_t chrom_len = HAP ? P.h.cell_size[ci] : P.g.chrom_len[ci];
+            if (chrom_len == 0) { err |= JK_KERR_EMPTY_CHROM; break; }
             double gl = jk_gamma(P.gp, gst, rng);
             if (gst.fail) { err |= JK_KERR_GAMMA_MATH; break; }
             frag_len = (uint64_t)gl;

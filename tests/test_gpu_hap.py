@@ -151,3 +151,22 @@ def test_tables_from_the_mutation_builder(ja, O):
     check(ja, O, hs, 150, 4000, 16, job())
     check(ja, O, hs, 100, 3001, 5, job(paired=False))
     check(ja, O, hs, 150, 2000, 7, job(matepair=True, frag_mean=700.0, frag_sd=80.0))
+
+
+def test_a_haplotype_that_lost_a_whole_chromosome(ja, O):
+    """A (haplotype, chromosome) cell without bases -- the chromosome deleted in one piece -- has probability 0 in that
+    haplotype's reads_per_group (src/hts_illumina.h:620-644, src/hts.h:78): its lanes skip it.  Also an empty reference
+    chromosome under haplotypes."""
+    from jackalope_amd.genome import HapBuilder
+    rng = np.random.default_rng(50)
+    seqs = [rng.choice(np.frombuffer(b"TCAG", dtype=np.uint8), size=n) for n in (9_000, 400, 0, 5_000)]
+    ref = ja.RefGenome(seqs)
+    b = HapBuilder(ref, 3)
+    b.add_del(2, 2, 1, 400)                      # haplotype 2 loses chromosome 2
+    b.add_sub(1, 1, 77, "G")
+    b.add_ins(3, 4, 4000, "TTAGC")
+    b.add_del(3, 1, 10, 9)
+    hs = b.snapshot()
+    assert hs.cells[1][1]["chrom_size"] == 0
+    check(ja, O, hs, 150, 6000, 23, job())
+    check(ja, O, hs, 100, 2001, 4, job(paired=False, prob_dup=0.2), barcodes=("AC", "GGTT", ""))

@@ -64,6 +64,14 @@ def test_other_error_models(ja, O):
     check_ref(ja, O, g, 400, 16, {"chi2_params_n": (0.0, 0.0, 5500)})      # n clamped to 0.001
 
 
+def test_empty_chromosomes_get_no_reads(ja, O):
+    """An empty chromosome has probability 0 in reads_per_group (src/hts.h:78); PacBio lanes take all their reads from their
+    first chromosome with a quota (src/hts_pacbio.cpp:145-151), which is never an empty one."""
+    rng = np.random.default_rng(47)
+    seqs = [rng.choice(np.frombuffer(b"TCAG", dtype=np.uint8), size=n) for n in (0, 120_000, 0, 40_000, 0)]
+    check_ref(ja, O, ja.RefGenome(seqs), 400, 12, {"custom_read_lengths": [500, 2500, 7000]})
+
+
 def test_non_tcag_bases_are_copied_like_the_reference(ja, O):
     rng = np.random.default_rng(45)
     seq = np.frombuffer(b"TCAGTCAGTCAGNnRY-\x00\x03", dtype=np.uint8)[rng.integers(0, 19, size=250_000)]

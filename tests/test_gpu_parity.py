@@ -78,6 +78,33 @@ def test_short_fragments_and_tiny_chromosomes(ja, O):
     check(ja, O, tiny, 150, 1500, 10, job(paired=False))
 
 
+def test_empty_chromosomes_get_no_reads(ja, O):
+    """A chromosome without bases has probability 0 in reads_per_group (src/hts.h:78 `continue`): no lane gets reads for it,
+    in any position of the list.  (Refused in rounds 1-2.)"""
+    rng = np.random.default_rng(21)
+    seqs = [rng.choice(np.frombuffer(b"TCAG", dtype=np.uint8), size=n) for n in (0, 30_000, 0, 0, 7_000, 151, 0)]
+    g = ja.RefGenome(seqs)
+    check(ja, O, g, 150, 6000, 37, job())
+    check(ja, O, g, 150, 3001, 5, job(paired=False, barcode="ACGTAC", prob_dup=0.3))
+    with pytest.raises(ja.JackalopeHipError, match="holds no bases"):
+        ja.illumina(ja.RefGenome([seqs[0], seqs[2]]), None, 10, 150, True, n_threads=1, seed_words=ja.seed_words(1, 16), _session=True)
+
+
+def test_refusals_name_their_reason(ja):
+    """The inputs this path refuses although the reference's C++ would take them: each ends the call
+    with JK_ERR_UNSUPPORTED and a message that says what to change."""
+    g = ja.synthetic_genome([20_000, 40], seed=22)
+    kw = dict(n_threads=2, seed_words=ja.seed_words(1, 64), _session=True)
+    # a fragment shorter than the barcode: `read_chrom_spaces[r] -= barcode.size()` wraps and `read[i] = barcode[i]` writes past
+    # the string in the reference (src/hts_illumina.cpp:177-182, :391): undefined there
+    with pytest.raises(ja.JackalopeHipError, match="shorter than the barcode .*chromosome of 40 bases against a barcode of 41") as e:
+        ja.illumina(g, None, 100, 150, True, barcodes="ACGTA" * 8 + "C", **kw)
+    assert e.value.code == 2            # JK_ERR_UNSUPPORTED
+    with pytest.raises(ja.JackalopeHipError, match="shorter than the barcode .*30 bases against a barcode of 32"):
+        ja.illumina(g, None, 100, 150, True, barcodes="ACGT" * 8, frag_len_min=30, **kw)
+    ja.illumina(g, None, 100, 150, True, barcodes="ACGT" * 10, **kw).close()          # 40 = the short chromosome: fine
+
+
 def test_many_chromosomes_use_binomial_quotas(ja, O):
     g = ja.synthetic_genome([30_000, 5_000, 80_000, 12_345, 150, 40_000, 999], seed=9)
     check(ja, O, g, 150, 20_000, 50, job())
