@@ -276,6 +276,12 @@ uint32_t jk_session_batches(const jk_session* s);
 /* PacBio: how often the last generate() re-planned its buffers and ran again (a lane's pool or the FASTQ image, both
  * sized from the read-length model, turned out too small; the kernels never write past either). */
 uint32_t jk_session_retries(const jk_session* s);
+/* Diagnostic (Illumina sessions): the generator decides `u < Prob[i]` of the alias step (src/alias_sampler.h:53-60) from the
+ * high 32 bits of the exact 64-bit cut point and reads the low 32 only when the draw's high word EQUALS the cut point's --
+ * once per 2^32 draws.  The lanes (relative to the shard) where that happened since the session was opened are noted, up to
+ * 61 of them; *n is the number of times it happened.  tests/test_gpu_full_size.py compares exactly those lanes with the
+ * oracle. */
+int jk_session_rare_branch_lanes(const jk_session* s, uint32_t* n, uint32_t* lanes, uint32_t cap);
 /* Number of sub-seed words consumed while opening the session. */
 uint64_t jk_session_seed_words_used(const jk_session* s);
 /* Positions [begin, end) in the seed-word stream of the add_n_reads words of this shard's lanes (after the

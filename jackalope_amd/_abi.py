@@ -115,7 +115,7 @@ EXPORTS = [
     "jk_illumina_ref_open", "jk_illumina_hap_open", "jk_pacbio_ref_open", "jk_pacbio_hap_open", "jk_session_generate", "jk_session_generate_async", "jk_session_wait", "jk_session_run", "jk_session_progress", "jk_session_sizes",
     "jk_session_device_ptr", "jk_session_fetch", "jk_session_fetch_range", "jk_session_write", "jk_session_write_shard",
     "jk_session_shard_seed_words", "jk_session_timing",
-    "jk_session_seed_words_used", "jk_session_retries", "jk_session_batches", "jk_session_lane_bytes", "jk_session_close",
+    "jk_session_seed_words_used", "jk_session_rare_branch_lanes", "jk_session_retries", "jk_session_batches", "jk_session_lane_bytes", "jk_session_close",
     "jk_split_int", "jk_reads_per_group", "jk_plan_lane_quotas", "jk_alias_build", "jk_hap_chrom_full",
     "jk_host_eval", "jk_dev_eval", "jk_eval_set_gamma", "jk_x87_one_minus",
     "jk_hap_builder_new", "jk_hap_builder_from", "jk_add_substitution", "jk_add_insertion", "jk_add_deletion",
@@ -184,6 +184,7 @@ def lib():
     L.jk_session_fetch_range.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
     L.jk_session_write_shard.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.jk_session_shard_seed_words.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.jk_session_rare_branch_lanes.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint32]
     L.jk_session_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.jk_session_lane_bytes.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
     L.jk_session_close.argtypes = [C.c_void_p]

@@ -169,6 +169,7 @@ static void launch_batches(jk_session& s, StreamCtx* sc, bool pipelined = false)
         }
         IlluminaKernelParams P = s.kp;
         P.err = err_ptr;
+        P.rare_log = s.d_err.as<uint32_t>() + 2; P.rare_lane0 = (uint32_t)B.lane0;
         P.n_lanes = B.n_lanes;
         P.seeds = s.d_seeds.as<uint32_t>() + B.lane0 * 8;
         P.lane_reads = s.d_lane_reads.as<uint64_t>() + B.lane0;

@@ -224,6 +224,19 @@ int jk_session_timing(const jk_session* s, double ms[3]) {
     });
 }
 
+int jk_session_rare_branch_lanes(const jk_session* s, uint32_t* n, uint32_t* lanes, uint32_t cap) {
+    return guarded([&] {
+        if (!s || !n) throw Error(JK_ERR_ARG, "NULL argument");
+        if (s->pacbio) throw Error(JK_ERR_ARG, "the rare-branch log belongs to the Illumina generator");
+        JK_HIP(hipSetDevice(s->device));
+        uint32_t log[1 + JK_RARE_LOG_CAP];
+        JK_HIP(hipDeviceSynchronize());
+        JK_HIP(hipMemcpy(log, s->d_err.as<uint32_t>() + 2, sizeof log, hipMemcpyDeviceToHost));
+        *n = log[0];
+        for (uint32_t i = 0; i < cap && i < log[0] && i < JK_RARE_LOG_CAP; i++) lanes[i] = log[1 + i];
+    });
+}
+
 uint64_t jk_session_seed_words_used(const jk_session* s) { return s ? s->seed_words_used : 0; }
 uint32_t jk_session_retries(const jk_session* s) { return s ? s->retries : 0; }
 uint32_t jk_session_batches(const jk_session* s) { return s ? (uint32_t)s->batches.size() : 0; }

@@ -36,6 +36,7 @@ constexpr int JK_MAX_EVW_LONG = 32;    // -- kernels with the tables in global m
 constexpr uint32_t JK_HAP_BUCKET_SHIFT = 10;   // 1024 haplotype positions per bucket of the mutation index
 constexpr uint32_t JK_HAP_SEGS = 3;    // segments of a read window kept in the per-lane LDS table (haplotype runs)
 
+constexpr uint32_t JK_RARE_LOG_CAP = 61;      // lanes IlluminaKernelParams::rare_log holds
 // error bits reported through IlluminaKernelParams::err
 enum : uint32_t {
     JK_KERR_IMAGE_FULL = 64u,          // the compacted FASTQ image would not fit the buffer allocated for it (PacBio: see plan_pools_common)
@@ -121,6 +122,9 @@ struct IlluminaKernelParams {
     // entries {cut point's high word, 8*char kept | 8*char of the alias << 16} (staged to LDS when LDS_TAB); tab_lo: the cut
     // points' low words, one per entry, read when a draw's high word equals its entry's (global memory)
     const uint32_t* tab; const uint64_t* mm2; const uint32_t* tab_lo;
+    // diagnostic: every time a cut point's low word decides (2^-32 per alias draw) the lane is noted -- [0] count, [1..JK_RARE_LOG_CAP]
+    // lanes of the session's shard -- so that a test can compare exactly those lanes with the oracle
+    uint32_t* rare_log; uint32_t rare_lane0;
     uint32_t n_info, n_entries;
     uint32_t lds_seg_off;                                  // HAP: byte offset of the per-lane segment table in LDS
     uint32_t lds_lut_off;                                  // packed reference: byte offset of the 512-entry expansion table in LDS
@@ -862,7 +866,11 @@ illumina_kernel(IlluminaKernelParams P) {
                 bool keep = x2h < th_hi;
                 if (__builtin_amdgcn_ballot_w64(x2h == th_hi) != 0) {
                     asm volatile("" ::: "memory");
-                    if (x2h == th_hi) keep = (uint32_t)x2 < P.tab_lo[(eoff - ent_base) >> 3];
+                    if (x2h == th_hi) {
+                        keep = (uint32_t)x2 < P.tab_lo[(eoff - ent_base) >> 3];
+                        const uint32_t k = atomicAdd(P.rare_log, 1u);
+                        if (k < JK_RARE_LOG_CAP) P.rare_log[1 + k] = P.rare_lane0 + lane;
+                    }
                 }
                 const uint32_t ch8 = keep ? (qp & 0xffffu) : (qp >> 16);
                 const uint64_t mmth = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(s_mm) + ch8);

@@ -202,6 +202,13 @@ class IlluminaSession:
     def retries(self):
         return int(_abi.lib().jk_session_retries(self._h))
 
+    def rare_branch_lanes(self):
+        """(count, lanes): how often a cut point's low word decided an alias draw since open, and in which lanes (up to 61)."""
+        n = C.c_uint32(0)
+        lanes = (C.c_uint32 * 61)()
+        _abi.check(_abi.lib().jk_session_rare_branch_lanes(self._h, C.byref(n), lanes, 61))
+        return int(n.value), [int(x) for x in lanes[:min(61, n.value)]]
+
     def lane_bytes(self, end, n_lanes):
         out = np.empty(n_lanes, dtype=np.uint64)
         _abi.check(_abi.lib().jk_session_lane_bytes(self._h, end, out.ctypes.data, n_lanes))

@@ -83,6 +83,36 @@ def test_full_size_config2(ja, O, hs25):
             assert r[e][a:a + n].tobytes() == o, "lanes %d..%d of R%d differ from the oracle" % (lo, hi, e + 1)
 
 
+def test_lanes_where_a_cut_points_low_word_decided(ja, O, hs25):
+    """The alias step's `u < Prob[i]` is decided from the high 32 bits of the exact 64-bit cut point; only a draw whose high
+    word EQUALS the cut point's reads the low word (global memory, csrc/jk_illumina_kernel.h `tab_lo`).  That is one alias
+    draw in 2^32 -- a 10 M-pair job makes 3.0e9 of them -- so no small case reaches the branch.  The generator notes the
+    lanes where it happened; this test runs headline-sized jobs until it has seen the branch at least twice and compares
+    exactly those lanes (and their neighbours) with the oracle."""
+    n_pairs, T = 10_000_000, 1 << 18
+    g = ja.synthetic_genome([100_000_000], seed=2)
+    j = job()
+    seen = 0
+    for rnd in range(8):
+        words = ja.seed_words(777 + rnd, 16 * T)
+        with open_hip(ja, g, (None, None), 150, words, 2 * n_pairs, T, j) as s:
+            s.generate()
+            n, lanes = s.rare_branch_lanes()
+            assert n == len(lanes) < 40                      # (expected 0.7 per job)
+            lb = [s.lane_bytes(e, T) for e in range(2)]
+            for lane in sorted(set(lanes)):
+                lo, hi = max(lane - 1, 0), min(lane + 2, T)
+                o1, o2, _ = run_oracle(O, g, hs25[0], hs25[1], words, 2 * n_pairs, T, j, thread_begin=lo, thread_end=hi)
+                for e, o in ((0, o1), (1, o2)):
+                    a, nb = int(lb[e][:lo].sum()), int(lb[e][lo:hi].sum())
+                    got = s.fetch_range(e, a, nb)
+                    assert bytes(got) == o, "lanes %d..%d of R%d (low-word branch in lane %d) differ from the oracle" % (lo, hi, e + 1, lane)
+            seen += n
+        if seen >= 2:
+            break
+    assert seen >= 2, "the low-word branch was never taken in %d jobs: is the log wired?" % (rnd + 1)
+
+
 def test_genome_offsets_beyond_4g(ja, O, hs25):
     """36 chromosomes of 125 Mbp = 4.5 Gbp at one byte per base: the last chromosomes sit beyond byte 2^32 of the
     device genome buffer, so every 64-bit address computation of the read fetch is exercised.  Whole job against the
