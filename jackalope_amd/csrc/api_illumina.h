@@ -277,6 +277,7 @@ static uint32_t plan_pools_common(jk_session& s, uint64_t max_batch_bytes, uint6
     s.d_block_sums.alloc((max_lanes / SCAN_BLOCK + 2) * 8);
     s.d_err.alloc(8 + 4 * (1 + JK_RARE_LOG_CAP));          // two steps' error words, then the generator's rare-branch log
     JK_HIP(hipMemset(s.d_err.p, 0, s.d_err.n));
+    s.setup_pending = true;
     for (hipEvent_t& e : s.step_end) if (!e) JK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t e : s.events) (void)hipEventDestroy(e);
     for (hipEvent_t e : s.gen_done) (void)hipEventDestroy(e);

@@ -81,6 +81,10 @@ static void complete_step(jk_session& s, StreamCtx* sc, int slot, bool stopped, 
 static void launch_batches(jk_session& s, StreamCtx* sc, bool pipelined = false) {
     JK_HIP(hipSetDevice(s.device));
     const int step_slot = s.next_slot;
+    // The set-up (open, re-plan) zeroes and fills buffers with hipMemset and small kernels on the null stream, which nothing
+    // orders against this session's non-blocking streams except the host having waited: most of that work is followed by
+    // a synchronous copy, but the first launch after a set-up does not rely on it.
+    if (s.setup_pending) { JK_HIP(hipStreamSynchronize(nullptr)); s.setup_pending = false; }
     uint32_t* const err_ptr = s.d_err.as<uint32_t>() + step_slot;
     JK_HIP(hipMemsetAsync(err_ptr, 0, 4, s.stream));
     if (s.inflight == 0) for (uint32_t e = 0; e < s.n_ends; e++) JK_HIP(hipMemsetAsync(s.d_base[e].p, 0, 8, s.stream));      // (entry 0 stays 0)

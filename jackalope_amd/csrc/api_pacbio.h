@@ -244,6 +244,7 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     s.d_block_sums.alloc((max_lanes / SCAN_BLOCK + 2) * 8);
     s.d_err.alloc(8);
     JK_HIP(hipMemset(s.d_err.p, 0, 8));
+    s.setup_pending = true;
     for (hipEvent_t& e : s.step_end) if (!e) JK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (hipEvent_t e : s.events) (void)hipEventDestroy(e);
     for (hipEvent_t e : s.gen_done) (void)hipEventDestroy(e);

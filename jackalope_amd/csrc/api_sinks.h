@@ -291,7 +291,7 @@ public:
         // (no thread may hold a task with this file's descriptor when it closes: the copier first, then the pipe's writers)
         stop_copier();
         if (pipe_) pipe_->quiesce();
-        if (zstream_) (void)hipStreamDestroy(zstream_);
+        if (zstream_) { (void)hipStreamSynchronize(zstream_); (void)hipStreamDestroy(zstream_); }     // (comp_ and the scratch are parked next)
         if (fd_ >= 0) ::close(fd_);
         if (gz_) gzclose(gz_);
     }

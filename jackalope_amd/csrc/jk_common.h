@@ -2,6 +2,8 @@
 // (part of the one translation unit jk_api.hip; see the include list there)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <cstdio>
@@ -28,7 +30,9 @@ static thread_local std::string g_last_error;
 // that is not known to be clean, at ~45 GB/s (tools/malloc_probe.hip), so a 100 GB set of pools costs seconds per
 // session when allocated afresh.  Parked memory counts as free in this library's own planning (dev_mem_info); when
 // hipMalloc fails the arena is emptied and the call repeated; jk_device_arena_trim() empties it on request, JK_ARENA=0
-// turns it off, JK_ARENA_POISON=1 fills every reused buffer with 0xa5 (tests: nothing may rely on fresh memory being zero).
+// turns it off, JK_ARENA_POISON=1 fills every reused buffer with 0xa5, =2 (or any larger number: a seed) with pseudo-random
+// words; either mode also fills what hipMalloc returns (tests: nothing may rely on fresh memory being zero, or on anything
+// else about it).
 struct DevArena {
     struct Item { void* p; size_t n; int dev; };
     std::mutex m;
@@ -74,6 +78,16 @@ struct DevArena {
     }
 };
 
+// JK_ARENA_POISON=2: a reused buffer is filled with pseudo-random words, different for every hand-out (0xa5 bytes make every
+// dword equal, which hides a reader that only trips over words that differ from each other)
+__global__ void arena_poison_kernel(uint32_t* p, uint64_t n_words, uint32_t seed) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t x = (uint32_t)i * 2654435761u ^ seed ^ (uint32_t)(i >> 32);
+        x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+        p[i] = x;
+    }
+}
+
 struct DevBuf {
     void* p = nullptr;
     size_t n = 0;          // bytes the owner asked for
@@ -99,8 +113,7 @@ struct DevBuf {
             size_t got = 0;
             if (void* q = DevArena::get().take(d, bytes, &got)) {
                 p = q; n = bytes; cap = got;
-                static const bool poison = std::getenv("JK_ARENA_POISON") && std::atoi(std::getenv("JK_ARENA_POISON")) != 0;
-                if (poison) JK_HIP(hipMemset(p, 0xa5, cap));
+                poison_fill();
                 return;
             }
         }
@@ -118,6 +131,20 @@ struct DevBuf {
         if (e != hipSuccess) { p = nullptr; throw Error(JK_ERR_DEVICE, std::string("hipMalloc of ") + std::to_string(bytes >> 20) + " MiB: " + hipGetErrorString(e)); }
         if (timed) std::fprintf(stderr, "[jk timing]   hipMalloc of %6.1f GB      %8.1f ms\n", bytes / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         n = bytes; cap = bytes;
+        poison_fill();              // (small buffers never see the arena, and hipMalloc hands back what this process freed a moment ago)
+    }
+    void poison_fill() {
+        static const int poison = std::getenv("JK_ARENA_POISON") ? std::atoi(std::getenv("JK_ARENA_POISON")) : 0;
+        if (!poison) return;
+        if (poison == 1) JK_HIP(hipMemset(p, 0xa5, cap));
+        else {
+            static std::atomic<uint32_t> round{0};
+            const uint64_t nw = (uint64_t)cap / 4;
+            hipLaunchKernelGGL(arena_poison_kernel, dim3((unsigned)std::min<uint64_t>(4096, (nw + 255) / 256 + 1)), dim3(256), 0, 0, static_cast<uint32_t*>(p), nw,
+                               0x9e3779b9u * (round.fetch_add(1) + (uint32_t)poison));
+            JK_HIP(hipGetLastError());
+        }
+        JK_HIP(hipDeviceSynchronize());
     }
     void swap(DevBuf& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); std::swap(dev, o.dev); }
     template <typename T> T* as() const { return static_cast<T*>(p); }

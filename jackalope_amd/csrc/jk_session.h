@@ -80,10 +80,16 @@ struct jk_session {
     std::vector<hipEvent_t> gen_done, cp_done;   // per batch, for the two-stream hand-off
     // steps (passes over all batches) in flight: at most two (jk_session_generate_async / jk_session_wait)
     int inflight = 0, next_slot = 0;
+    bool setup_pending = true;             // set-up work (memsets, small kernels) was queued on the null stream since the last launch
     hipEvent_t step_end[2] = {nullptr, nullptr};
     size_t pending_ev[2] = {0, 0};
 
     ~jk_session() {
+        // (the buffers below go to the device arena, not to hipFree, which would wait for the device: nothing of this session
+        //  may still be running when the next session is handed them)
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (cp_stream) (void)hipStreamSynchronize(cp_stream);
+        if (stream2) (void)hipStreamSynchronize(stream2);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         for (hipEvent_t e : gen_done) (void)hipEventDestroy(e);
         for (hipEvent_t e : cp_done) (void)hipEventDestroy(e);
