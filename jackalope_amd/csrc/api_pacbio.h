@@ -144,7 +144,9 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     // image per launch: the scratch is an eighth of that), since a lane's reads cannot be spread over launches.
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s.device);
-    const uint64_t slots = (uint64_t)n_cu * 16;
+    uint64_t waves_per_cu = 16;
+    if (const char* e = std::getenv("JK_PB_WAVES_PER_CU")) { const int v = std::atoi(e); if (v >= 4 && v <= 16 && v % 4 == 0) waves_per_cu = (uint64_t)v; }
+    const uint64_t slots = (uint64_t)n_cu * waves_per_cu;
     uint64_t batch_bytes = max_batch_bytes ? max_batch_bytes : (16ULL << 30);
     uint64_t max_batch_lanes = 1ULL << 18;
     uint32_t wave_lanes = 64;

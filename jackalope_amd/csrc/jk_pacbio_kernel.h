@@ -751,32 +751,36 @@ pb_emit_kernel(PbEmitParams P) {
     // the image is allocated for the expected size: never write past it
     if (at + out_len > P.out_cap) { if (lid == 0) atomicOr(P.err, JK_KERR_IMAGE_FULL); return; }
 
-    // ---- the text writer: g = global address of the next byte, `flushed` = the first byte still in the ring
-    uint64_t g = (uint64_t)(uintptr_t)(P.out + at), flushed = g;
-    auto put = [&](uint32_t off, uint32_t byte) { ring[((uint32_t)g + off) & (PB_RING - 1u)] = (uint8_t)byte; };
+    // ---- the text writer: g = the next byte, `flushed` = the first byte still in the ring, both as offsets from `gbase`,
+    // the ring-aligned address below the record's first byte (32 bits: a record is shorter than 2^32 bytes; the kernel's
+    // bookkeeping is scalar work, and 64-bit scalar arithmetic is two instructions per operation)
+    const uint64_t gaddr0 = (uint64_t)(uintptr_t)(P.out + at);
+    const uint64_t gbase = gaddr0 & ~(uint64_t)(PB_RING - 1u);
+    uint32_t g = (uint32_t)(gaddr0 - gbase), flushed = g;
+    auto put = [&](uint32_t off, uint32_t byte) { ring[(g + off) & (PB_RING - 1u)] = (uint8_t)byte; };
     // write out the ring's bytes [flushed, upto) of the 1 KB-aligned segment that holds `flushed` (upto <= its end)
-    auto flush_segment = [&](uint64_t upto) {
+    auto flush_segment = [&](uint32_t upto) {
         __syncthreads();
-        const uint64_t seg = flushed & ~1023ULL;
+        const uint32_t seg = flushed & ~1023u;
         if (flushed == seg && upto == seg + 1024u) {         // a whole segment (all but the first and last of a read)
-            const uint4 v = *reinterpret_cast<const uint4*>(ring + ((uint32_t)seg & (PB_RING - 1u)) + 16u * lid);
-            reinterpret_cast<uint4*>((uintptr_t)seg)[lid] = v;
+            const uint4 v = *reinterpret_cast<const uint4*>(ring + (seg & (PB_RING - 1u)) + 16u * lid);
+            reinterpret_cast<uint4*>((uintptr_t)(gbase + seg))[lid] = v;
         } else {
-            const uint64_t pa = seg + 16u * lid;                 // this lane's 16-byte piece
-            const uint64_t plo = pa > flushed ? pa : flushed, phi = pa + 16u < upto ? pa + 16u : upto;
+            const uint32_t pa = seg + 16u * lid;                 // this lane's 16-byte piece
+            const uint32_t plo = pa > flushed ? pa : flushed, phi = pa + 16u < upto ? pa + 16u : upto;
             if (plo < phi) {
                 if (phi - plo == 16u) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(ring + ((uint32_t)pa & (PB_RING - 1u)));
-                    *reinterpret_cast<uint4*>((uintptr_t)pa) = v;
+                    const uint4 v = *reinterpret_cast<const uint4*>(ring + (pa & (PB_RING - 1u)));
+                    *reinterpret_cast<uint4*>((uintptr_t)(gbase + pa)) = v;
                 } else {
-                    for (uint64_t a = plo; a < phi; a++) *reinterpret_cast<uint8_t*>((uintptr_t)a) = ring[(uint32_t)a & (PB_RING - 1u)];
+                    for (uint32_t a = plo; a < phi; a++) *reinterpret_cast<uint8_t*>((uintptr_t)(gbase + a)) = ring[a & (PB_RING - 1u)];
                 }
             }
         }
         flushed = upto;
         __syncthreads();
     };
-    auto flush_full = [&]() { while (g - (flushed & ~1023ULL) >= 1024u) flush_segment((flushed & ~1023ULL) + 1024u); };
+    auto flush_full = [&]() { while (g - (flushed & ~1023u) >= 1024u) flush_segment((flushed & ~1023u) + 1024u); };
 
     // ---- id line: "@<genome>-<chromosome>-" + start + "-F\n" / "-R\n"
     for (uint32_t i0 = 0; i0 < hlen; i0 += 64u) {
@@ -851,9 +855,8 @@ pb_emit_kernel(PbEmitParams P) {
     // that this is not the read's last block -- true for all but the last few blocks of a read, and it takes the
     // end-of-read, end-of-window and flush tests (scalar instructions: a SIMD issues one per four clocks, like vector
     // ones, and this kernel has as many of them) out of the block.
-    auto do_block = [&](uint32_t b, uint32_t q, uint32_t wsrc, auto safe_tag) {
+    auto do_block = [&](uint32_t b, uint32_t q, uint32_t wsrc, uint32_t mvx, uint32_t mvy, uint32_t mvz, uint32_t mvw, auto safe_tag) {
         constexpr bool SAFE = decltype(safe_tag)::value;
-        const uint32_t mvx = cmasks[b].x, mvy = cmasks[b].y, mvz = cmasks[b].z, mvw = cmasks[b].w;
         const uint64_t lo = (uint64_t)mvx | ((uint64_t)mvy << 32), hi = (uint64_t)mvz | ((uint64_t)mvw << 32);
         const uint64_t insm = lo & ~hi, delm = hi & ~lo, keep = ~delm;
         const uint32_t off = pb_mbcnt(insm, pb_mbcnt(keep, 0u));          // bases the positions below this lane's add
@@ -938,7 +941,7 @@ pb_emit_kernel(PbEmitParams P) {
             ch = my_sub ? sub_ch : bch;
             ich = is_nul ? 0u : base_char(c4);
         }
-        const uint32_t ri = ((uint32_t)g + off) & (PB_RING - 1u);
+        const uint32_t ri = (g + off) & (PB_RING - 1u);
         if (__builtin_amdgcn_inverse_ballot_w64(kp)) ring[ri] = (uint8_t)ch;
         if (__builtin_amdgcn_inverse_ballot_w64(ip)) ring[(ri + 1u) & (PB_RING - 1u)] = (uint8_t)ich;
         const uint32_t nb = (uint32_t)__builtin_popcountll(kp) + (uint32_t)__builtin_popcountll(ip);
@@ -949,14 +952,17 @@ pb_emit_kernel(PbEmitParams P) {
         const uint32_t wnext = (b0 + 4u < nblk) ? load_group((b0 + 4u) * 64u) : 0u;      // (requested a group ahead)
         // a group of four blocks that cannot reach the end of the read (a block adds at most 128 bases) or of the window
         if (cur + 512u <= L && (b0 + 4u) * 64u <= space && b0 + 4u < nblk) {
+            // (the four blocks' masks as one 64-byte scalar load: a read's blocks start on a 64-byte line)
+            typedef uint32_t pb_u16v __attribute__((ext_vector_type(16)));
+            const pb_u16v mg = *reinterpret_cast<const pb_u16v __attribute__((address_space(4)))*>(cmasks + b0);
 #pragma unroll
-            for (uint32_t q = 0; q < 4u; q++) do_block(b0 + q, q, wsrc, std::true_type());
+            for (uint32_t q = 0; q < 4u; q++) do_block(b0 + q, q, wsrc, mg[4 * q], mg[4 * q + 1], mg[4 * q + 2], mg[4 * q + 3], std::true_type());
             flush_full();                      // (at most 1023 + 512 bytes are pending here: the ring holds 2048)
         } else {
 #pragma unroll
             for (uint32_t q = 0; q < 4u; q++) {
                 if (b0 + q >= nblk || cur >= L) break;
-                do_block(b0 + q, q, wsrc, std::false_type());
+                do_block(b0 + q, q, wsrc, cmasks[b0 + q].x, cmasks[b0 + q].y, cmasks[b0 + q].z, cmasks[b0 + q].w, std::false_type());
                 flush_full();
             }
         }
@@ -969,7 +975,7 @@ pb_emit_kernel(PbEmitParams P) {
     g += 3u;
     flush_full();
     if (g > flushed) flush_segment(g);
-    uint8_t* const ql = reinterpret_cast<uint8_t*>((uintptr_t)g);
+    uint8_t* const ql = reinterpret_cast<uint8_t*>((uintptr_t)(gbase + g));
     if (lid == 0) ql[L] = '\n';
     const uint32_t q_left = (R.flags >> 8) & 0xffu, q_right = (R.flags >> 16) & 0xffu, split = R.split;
     // 16-byte pieces at 16-byte aligned addresses; the pieces at the ends and the one across the split byte by byte
