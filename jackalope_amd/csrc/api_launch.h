@@ -162,6 +162,8 @@ static void launch_batches(jk_session& s, StreamCtx* sc, bool pipelined = false)
             E.masks = Q.masks; E.stale = Q.stale; E.jump = Q.jump;
             E.out = out_img[0]; E.out_base = out_base[0]; E.out_cap = out_cap;
             E.err = err_ptr;
+            // (JK_PB_FORCE_EXACT=1, tests: every buffer of draws goes through the exact index routine and the general block)
+            E.exact_from = (std::getenv("JK_PB_FORCE_EXACT") && std::atoi(std::getenv("JK_PB_FORCE_EXACT")) != 0) ? 0u : 0xfffffff0u;
             if (B.n_reads) {
                 if (Q.hap_seg) hipLaunchKernelGGL((pb_emit_kernel<true>), dim3((uint32_t)B.n_reads), dim3(64), 0, s.cp_stream, E);
                 else hipLaunchKernelGGL((pb_emit_kernel<false>), dim3((uint32_t)B.n_reads), dim3(64), 0, s.cp_stream, E);

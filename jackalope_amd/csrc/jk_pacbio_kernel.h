@@ -119,6 +119,7 @@ struct PbEmitParams {
     const uint4* masks; const uint8_t* stale; const uint64_t* jump;
     uint8_t* out; const uint64_t* out_base; uint64_t out_cap;
     uint32_t* err;
+    uint32_t exact_from;          // a draw whose scaled high word reaches this takes the exact index routine (0xfffffff0; tests: 0 = all)
 };
 
 // Exact integer cut points of the comparisons pass 1 makes against a per-read probability c:
@@ -821,17 +822,29 @@ pb_emit_kernel(PbEmitParams P) {
     }
     uint64_t dc_lo, dc_hi;
     { const jk_u128 C64 = PB_G64 * I; dc_lo = (uint64_t)C64; dc_hi = (uint64_t)(C64 >> 64); asm volatile("" : "+v"(dc_lo), "+v"(dc_hi)); }
-    uint32_t xb_lo = 0, xb_hi = 0, pk = 0;        // lane j: draw number j of the current buffer: raw words, {index of 3, index of 4 << 8}
-    bool xb_exact = false;                        // some draw of the buffer needs runif_index32
-    auto make_buffer = [&]() {
+    // Two buffers of 64 draws are kept, A (draws 0..63 of the window) and B (64..127): lane j holds draw j of each as raw
+    // words and as the packed word {index of 3, index of 4 << 8}.  `used` counts the draws of A handed out (< 64 whenever a
+    // block starts), so a block -- at most 64 draws -- finds its draws in A and B without refilling; when A is used up, B
+    // becomes A and a new B is made (one multiply-add by M^64 per lane).
+    uint32_t xa_lo = 0, xa_hi = 0, pka = 0, xb_lo = 0, xb_hi = 0, pkb = 0;
+    bool xa_exact = false, xb_exact = false;      // some draw of the buffer needs runif_index32
+    auto make_buffer = [&](uint32_t& x_lo, uint32_t& x_hi, uint32_t& pk, bool& ex) {
         const uint64_t xv = pb_pcg_out(ds0, ds1, ds2, ds3);
-        xb_lo = (uint32_t)xv; xb_hi = (uint32_t)(xv >> 32);
-        const uint32_t p3 = xb_hi * 3u;
-        pk = __umulhi(xb_hi, 3u) | ((xb_hi >> 30) << 8);
-        xb_exact = __builtin_amdgcn_ballot_w64(p3 >= 0xfffffff0u || (xb_hi << 2) >= 0xfffffff0u) != 0;
+        x_lo = (uint32_t)xv; x_hi = (uint32_t)(xv >> 32);
+        const uint32_t p3 = x_hi * 3u;
+        pk = __umulhi(x_hi, 3u) | ((x_hi >> 30) << 8);
+        ex = __builtin_amdgcn_ballot_w64(p3 >= P.exact_from || (x_hi << 2) >= P.exact_from) != 0;
     };
-    make_buffer();
-    uint32_t used = 0;                            // draws of the buffer already handed out
+    make_buffer(xa_lo, xa_hi, pka, xa_exact);
+    pb_pcg_mad64(ds0, ds1, ds2, ds3, dc_lo, dc_hi);
+    make_buffer(xb_lo, xb_hi, pkb, xb_exact);
+    uint32_t used = 0;                            // draws of A already handed out
+    auto next_buffer = [&]() {
+        xa_lo = xb_lo; xa_hi = xb_hi; pka = pkb; xa_exact = xb_exact;
+        pb_pcg_mad64(ds0, ds1, ds2, ds3, dc_lo, dc_hi);
+        make_buffer(xb_lo, xb_hi, pkb, xb_exact);
+        used -= 64u;
+    };
     const uint64_t coff = P.g.chrom_off[SEG ? R.ci % P.n_chroms : R.ci];
     const uint8_t* const gseq = P.g.seq;
     // forward: position p of the window is the byte at A + p; reverse: the complement of the one at A - p
@@ -866,44 +879,29 @@ pb_emit_kernel(PbEmitParams P) {
         const uint64_t evm = lo & pm;                                     // insertions and substitutions among them: one draw each
         // ---- this block's draws, in position order (src/hts_pacbio.cpp:384-395): consecutive outputs of the stream by rank
         // substitution: mm_nucleos[nt][(uint64)(runif_01 * 3)]; insertion: jlp::bases[(uint64)(runif_01 * 4)]
-        uint32_t pkv = 0;
+        // (a SAFE block belongs to a group whose draws were counted beforehand: they all lie in A and B, and neither buffer
+        //  holds a draw that needs the exact routine -- no decision is left in the block)
         uint64_t nulm = 0;                                                // draws that index past their string: its NUL
-        if (evm != 0) {
-            const uint32_t d = used + pb_mbcnt(evm, 0u);
-            const uint32_t ne = (uint32_t)__builtin_popcountll(evm);
-            const int baddr = (int)((d << 2) & 0xfcu);                    // (the same for draw d of this buffer and draw d - 64 of the next)
-            bool exact = xb_exact;
-            uint32_t o_lo = 0, o_hi = 0;
-            const bool two = used + ne > 64u;
-            if (!two) pkv = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)pk);
-            else {
-                const uint32_t p1 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)pk);     // (meaningful where d < 64)
-                o_lo = xb_lo; o_hi = xb_hi;
-                pb_pcg_mad64(ds0, ds1, ds2, ds3, dc_lo, dc_hi);
-                make_buffer();
-                const uint32_t p2 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)pk);
-                pkv = d < 64u ? p1 : p2;
-                exact = exact || xb_exact;
-                used -= 64u;
-            }
-            used += ne;
-            if (exact) {
-                asm volatile("" ::: "memory");
-                uint32_t xh, xl;
-                if (!two) { xh = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xb_hi); xl = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xb_lo); }
-                else {
-                    const uint32_t h1 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)o_hi), l1 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)o_lo);
-                    const uint32_t h2 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xb_hi), l2 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xb_lo);
-                    xh = d < 64u ? h1 : h2;
-                    xl = d < 64u ? l1 : l2;
-                }
-                const bool is_sub = __builtin_amdgcn_inverse_ballot_w64(sp);
-                const uint32_t nidx = is_sub ? 3u : 4u;
-                const uint32_t code = runif_index32(((uint64_t)xh << 32) | xl, nidx);
-                nulm = __builtin_amdgcn_ballot_w64(code >= nidx) & evm;
-                pkv = (code & 3u) | ((code & 3u) << 8);
-            }
+        const uint32_t ne = (uint32_t)__builtin_popcountll(evm);
+        const uint32_t d = used + pb_mbcnt(evm, 0u);                      // this lane's draw, if it has one: 0..127
+        const int baddr = (int)((d << 2) & 0xfcu);                        // (the same for draw d of A and draw d - 64 of B)
+        uint32_t pkv;
+        {
+            const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)pka), pb = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)pkb);
+            pkv = d < 64u ? pa : pb;
         }
+        if (!SAFE && ne != 0u && (xa_exact || xb_exact)) {
+            asm volatile("" ::: "memory");
+            const uint32_t h1 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xa_hi), l1 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xa_lo);
+            const uint32_t h2 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xb_hi), l2 = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)xb_lo);
+            const uint32_t xh = d < 64u ? h1 : h2, xl = d < 64u ? l1 : l2;
+            const bool is_sub = __builtin_amdgcn_inverse_ballot_w64(sp);
+            const uint32_t nidx = is_sub ? 3u : 4u;
+            const uint32_t code = runif_index32(((uint64_t)xh << 32) | xl, nidx);
+            nulm = __builtin_amdgcn_ballot_w64(code >= nidx) & evm;
+            pkv = (code & 3u) | ((code & 3u) << 8);
+        }
+        used += ne;
         // ---- source base
         const uint32_t p = b * 64u + lid;
         uint32_t craw = 0;
@@ -918,7 +916,8 @@ pb_emit_kernel(PbEmitParams P) {
             craw = (wq >> bsh) & 0xffu;
         }
         const uint64_t outm = (SAFE || b * 64u + 64u <= space) ? 0ULL : __builtin_amdgcn_ballot_w64(p >= space);     // positions past the window
-        const uint64_t oddm = (__builtin_amdgcn_ballot_w64(craw >= 4u) | outm | nulm) & pm;
+        // (SAFE, reference / materialised haplotypes: the group's 256 source bytes were tested at once)
+        const uint64_t oddm = (SAFE && !SEG) ? 0ULL : (__builtin_amdgcn_ballot_w64(craw >= 4u) | outm | nulm) & pm;
         const uint32_t c = craw ^ rcm;                                    // (complemented on the reverse strand, if it is a base)
         const bool my_sub = __builtin_amdgcn_inverse_ballot_w64(sp);
         uint32_t ch, ich;
@@ -946,18 +945,30 @@ pb_emit_kernel(PbEmitParams P) {
         if (__builtin_amdgcn_inverse_ballot_w64(ip)) ring[(ri + 1u) & (PB_RING - 1u)] = (uint8_t)ich;
         const uint32_t nb = (uint32_t)__builtin_popcountll(kp) + (uint32_t)__builtin_popcountll(ip);
         cur += nb; g += nb;
+        if (!SAFE && used >= 64u) next_buffer();
     };
     uint32_t wsrc = load_group(0);
     for (uint32_t b0 = 0; b0 < nblk && cur < L; b0 += 4u) {
         const uint32_t wnext = (b0 + 4u < nblk) ? load_group((b0 + 4u) * 64u) : 0u;      // (requested a group ahead)
         // a group of four blocks that cannot reach the end of the read (a block adds at most 128 bases) or of the window
-        if (cur + 512u <= L && (b0 + 4u) * 64u <= space && b0 + 4u < nblk) {
+        bool fast = cur + 512u <= L && (b0 + 4u) * 64u <= space && b0 + 4u < nblk;
+        typedef uint32_t pb_u16v __attribute__((ext_vector_type(16)));
+        pb_u16v mg = {};
+        if (fast) {
             // (the four blocks' masks as one 64-byte scalar load: a read's blocks start on a 64-byte line)
-            typedef uint32_t pb_u16v __attribute__((ext_vector_type(16)));
-            const pb_u16v mg = *reinterpret_cast<const pb_u16v __attribute__((address_space(4)))*>(cmasks + b0);
+            mg = *reinterpret_cast<const pb_u16v __attribute__((address_space(4)))*>(cmasks + b0);
+            // ... and the group's draws fit the two buffers, none of which needs the exact routine, and its 256 source bytes
+            // are plain bases (lane l holds four of them)
+            const uint32_t nd4 = (uint32_t)__builtin_popcountll((uint64_t)mg[0] | ((uint64_t)mg[1] << 32)) + (uint32_t)__builtin_popcountll((uint64_t)mg[4] | ((uint64_t)mg[5] << 32)) +
+                                 (uint32_t)__builtin_popcountll((uint64_t)mg[8] | ((uint64_t)mg[9] << 32)) + (uint32_t)__builtin_popcountll((uint64_t)mg[12] | ((uint64_t)mg[13] << 32));
+            fast = used + nd4 <= 128u && !xa_exact && !xb_exact && (SEG || __builtin_amdgcn_ballot_w64((wsrc & 0xfcfcfcfcu) != 0u) == 0);
+        }
+        if (fast) {
 #pragma unroll
             for (uint32_t q = 0; q < 4u; q++) do_block(b0 + q, q, wsrc, mg[4 * q], mg[4 * q + 1], mg[4 * q + 2], mg[4 * q + 3], std::true_type());
             flush_full();                      // (at most 1023 + 512 bytes are pending here: the ring holds 2048)
+            if (used >= 64u) next_buffer();    // (used <= 128 here)
+            if (used >= 64u) next_buffer();
         } else {
 #pragma unroll
             for (uint32_t q = 0; q < 4u; q++) {

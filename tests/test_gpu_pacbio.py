@@ -163,3 +163,26 @@ def test_sep_files_and_compressed_sink(ja, O, tmp_path):
         assert raw[12:14] == b"BC"                 # BGZF blocks (made on the device)
         total += len(fastq_records(o))
     assert total == n
+
+
+def test_exact_index_routine_for_every_draw(ja, O, monkeypatch):
+    """The emit kernel turns a draw into an index of 3 or 4 from its high word and sends a whole buffer of 64 draws through
+    the exact routine (runif_index32) only when one of them lies within 16 units of a boundary -- 2^-28 per draw, which no
+    small case reaches.  JK_PB_FORCE_EXACT=1 sends every buffer that way (and every block through the general path): same
+    bytes.  Jobs with many draws per block (high insertion / substitution rates: blocks whose draws span both buffers),
+    duplicates, haplotypes through the tables and reads that over-read their window."""
+    monkeypatch.setenv("JK_PB_FORCE_EXACT", "1")
+    g = ja.synthetic_genome([300_000, 10_000], seed=48)
+    check_ref(ja, O, g, 500, 16, {"custom_read_lengths": [300, 1200, 5000, 20000]})
+    check_ref(ja, O, g, 300, 8, {"ins_prob": 0.3, "del_prob": 0.2, "sub_prob": 0.3, "prob_dup": 0.3, "read_pool_size": 5})
+    tiny = ja.synthetic_genome([2500, 900], seed=49)
+    check_ref(ja, O, tiny, 400, 3, {"custom_read_lengths": [800, 2500], "prob_dup": 0.5})
+
+
+def test_blocks_whose_draws_span_both_buffers(ja, O):
+    """Event rates at which most 64-position blocks hold dozens of draws (the fast groups must count them and stay within
+    the 128 draws at hand), next to rates at which hardly any block holds one."""
+    g = ja.synthetic_genome([400_000], seed=50)
+    check_ref(ja, O, g, 400, 8, {"ins_prob": 0.45, "del_prob": 0.05, "sub_prob": 0.45, "custom_read_lengths": [3000, 9000]})
+    check_ref(ja, O, g, 400, 8, {"ins_prob": 0.001, "del_prob": 0.001, "sub_prob": 0.001, "custom_read_lengths": [3000, 9000]})
+    check_ref(ja, O, g, 400, 8, {"ins_prob": 1e-6, "del_prob": 1e-6, "sub_prob": 1e-6, "custom_read_lengths": [6000]})
