@@ -66,6 +66,7 @@ struct PbRead {
 JK_HD uint32_t jk_dec_digits(uint64_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; d++; } return d; }
 constexpr uint32_t PB_HIST = 16;              // depth of the per-lane history of buffer-covering reads (see pb_plan_kernel)
 constexpr uint32_t PB_PLAN_BLOCK = 256;       // 4 independent waves
+constexpr uint32_t PB_SRC_CHUNK = 1024;       // window bytes pb_emit_kernel brings to LDS at a time (16 blocks of 64 positions)
 constexpr uint32_t PB_MASK_CHUNK = 4096;      // 16-byte mask blocks a wave takes from the arena at a time (64 KB)
 
 // pcg64's multiplier to the k-th power and 1 + M + ... + M^(k-1): the state k steps ahead is M^k s + G_k inc
@@ -737,6 +738,7 @@ template <bool SEG>
 __global__ void __launch_bounds__(64)
 pb_emit_kernel(PbEmitParams P) {
     __shared__ __align__(16) uint8_t ring[PB_RING];
+    __shared__ __align__(16) uint8_t srcb[2 * PB_SRC_CHUNK];     // the window's bytes, two chunks of 1 KB in turn (see stage_chunk)
     const uint32_t r = blockIdx.x;
     if (r >= P.n_recs) return;
     const PbRead R = P.recs[r];
@@ -850,25 +852,36 @@ pb_emit_kernel(PbEmitParams P) {
     // forward: position p of the window is the byte at A + p; reverse: the complement of the one at A - p
     const uint64_t A = coff + (reverse ? R.read_start + space - 1u : R.read_start);
     const uint32_t rcm = reverse ? 2u : 0u;
-    const uint32_t bsh = 8u * (reverse ? 3u - (lid & 3u) : (lid & 3u));      // where this lane's base sits in the dword dealt to it
-    const uint32_t bad0 = lid & ~3u;                                          // ds_bpermute address of that dword, block 0 of a group
     const pb_cmask_t cmasks = (pb_cmask_t)(uintptr_t)(P.masks + R.mask_idx);
     uint32_t cur = 0;                             // bases written so far
     const uint32_t nblk = (R.n_pos + 63u) >> 6;
-    // the window's bytes for 256 positions: lane l holds positions 4l .. 4l+3 of the group (reverse: in descending address order)
-    auto load_group = [&](uint32_t p0) -> uint32_t {
-        uint32_t w = 0;
-        if (!SEG && p0 + 4u * lid < space) {
-            const uint8_t* a = reverse ? gseq + (A - p0 - 4u * lid - 3u) : gseq + (A + p0 + 4u * lid);
-            __builtin_memcpy(&w, a, 4);
+    // The window's bytes come through LDS, 1 KB (16 blocks) at a time: every lane loads 16 bytes of the next chunk while the
+    // current one is worked on, and they are put down at the end of the current chunk.  gfx950 counts vector loads and stores
+    // with one counter and lets them complete out of order, so waiting for ANY load waits for every store issued before the
+    // wait -- with a load per group of four blocks the wave stood still for a store's whole latency forty times per 10-kb
+    // read (9.3 ms per launch, of which 6 were instruction issue); now it does so once per sixteen blocks.
+    // Position p of the window is byte (p & 2047) ^ rx of `srcb` (reverse strand: a lane's 16 bytes lie in ascending address
+    // order, i.e. in descending position order: rx = 15).
+    const uint32_t rx = reverse ? 15u : 0u;
+    auto load_chunk = [&](uint32_t c) -> uint4 {
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t p0 = c * PB_SRC_CHUNK + 16u * lid;
+        if (!SEG && p0 < space) {
+            const uint8_t* a = reverse ? gseq + (A - p0 - 15u) : gseq + (A + p0);
+            __builtin_memcpy(&w, a, 16);
         }
         return w;
     };
+    auto stage_chunk = [&](uint32_t c, const uint4& w) { *reinterpret_cast<uint4*>(srcb + (c & 1u) * PB_SRC_CHUNK + 16u * lid) = w; };
+    const uint32_t n_chunks = SEG ? 0u : (space + PB_SRC_CHUNK - 1u) / PB_SRC_CHUNK;
+    if (n_chunks > 0u) stage_chunk(0u, load_chunk(0u));
+    uint4 nxt = n_chunks > 1u ? load_chunk(1u) : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t src_lane = (uint32_t)(uintptr_t)srcb + (lid ^ rx);         // LDS address of this lane's byte of block 0
     // One block of 64 positions.  SAFE: the caller knows that the walk visits all 64, that they lie inside the window and
     // that this is not the read's last block -- true for all but the last few blocks of a read, and it takes the
     // end-of-read, end-of-window and flush tests (scalar instructions: a SIMD issues one per four clocks, like vector
     // ones, and this kernel has as many of them) out of the block.
-    auto do_block = [&](uint32_t b, uint32_t q, uint32_t wsrc, uint32_t mvx, uint32_t mvy, uint32_t mvz, uint32_t mvw, auto safe_tag) {
+    auto do_block = [&](uint32_t b, uint32_t mvx, uint32_t mvy, uint32_t mvz, uint32_t mvw, auto safe_tag) {
         constexpr bool SAFE = decltype(safe_tag)::value;
         const uint64_t lo = (uint64_t)mvx | ((uint64_t)mvy << 32), hi = (uint64_t)mvz | ((uint64_t)mvw << 32);
         const uint64_t insm = lo & ~hi, delm = hi & ~lo, keep = ~delm;
@@ -912,8 +925,7 @@ pb_emit_kernel(PbEmitParams P) {
                 craw = gseq[hap_resolve(P.h, coff, R.ci, m, hpos).addr];
             }
         } else {
-            const uint32_t wq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(bad0 + 64u * q), (int)wsrc);
-            craw = (wq >> bsh) & 0xffu;
+            craw = *reinterpret_cast<const __attribute__((address_space(3))) uint8_t*>((uintptr_t)(src_lane + ((b * 64u) & (2u * PB_SRC_CHUNK - 1u))));
         }
         const uint64_t outm = (SAFE || b * 64u + 64u <= space) ? 0ULL : __builtin_amdgcn_ballot_w64(p >= space);     // positions past the window
         // (SAFE, reference / materialised haplotypes: the group's 256 source bytes were tested at once)
@@ -947,11 +959,9 @@ pb_emit_kernel(PbEmitParams P) {
         cur += nb; g += nb;
         if (!SAFE && used >= 64u) next_buffer();
     };
-    uint32_t wsrc = load_group(0);
     for (uint32_t b0 = 0; b0 < nblk && cur < L; b0 += 4u) {
-        const uint32_t wnext = (b0 + 4u < nblk) ? load_group((b0 + 4u) * 64u) : 0u;      // (requested a group ahead)
-        // a group of four blocks that cannot reach the end of the read (a block adds at most 128 bases) or of the window
-        bool fast = cur + 512u <= L && (b0 + 4u) * 64u <= space && b0 + 4u < nblk;
+        // a group of four blocks inside the window that does not reach the end of the read
+        bool fast = cur + 256u < L && (b0 + 4u) * 64u <= space && b0 + 4u < nblk;
         typedef uint32_t pb_u16v __attribute__((ext_vector_type(16)));
         pb_u16v mg = {};
         if (fast) {
@@ -961,11 +971,23 @@ pb_emit_kernel(PbEmitParams P) {
             // are plain bases (lane l holds four of them)
             const uint32_t nd4 = (uint32_t)__builtin_popcountll((uint64_t)mg[0] | ((uint64_t)mg[1] << 32)) + (uint32_t)__builtin_popcountll((uint64_t)mg[4] | ((uint64_t)mg[5] << 32)) +
                                  (uint32_t)__builtin_popcountll((uint64_t)mg[8] | ((uint64_t)mg[9] << 32)) + (uint32_t)__builtin_popcountll((uint64_t)mg[12] | ((uint64_t)mg[13] << 32));
-            fast = used + nd4 <= 128u && !xa_exact && !xb_exact && (SEG || __builtin_amdgcn_ballot_w64((wsrc & 0xfcfcfcfcu) != 0u) == 0);
+            bool plain = true;
+            if (!SEG) {
+                const uint32_t w4 = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>((uintptr_t)((uint32_t)(uintptr_t)srcb + ((b0 * 64u) & (2u * PB_SRC_CHUNK - 1u)) + 4u * lid));
+                plain = __builtin_amdgcn_ballot_w64((w4 & 0xfcfcfcfcu) != 0u) == 0;
+            }
+            // (bases the group adds: a position gives one unless it is deleted, and one more if it carries an insertion)
+            uint32_t nb4 = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) {
+                const uint64_t lo_ = (uint64_t)mg[4 * q] | ((uint64_t)mg[4 * q + 1] << 32), hi_ = (uint64_t)mg[4 * q + 2] | ((uint64_t)mg[4 * q + 3] << 32);
+                nb4 += (uint32_t)__builtin_popcountll(~(hi_ & ~lo_)) + (uint32_t)__builtin_popcountll(lo_ & ~hi_);
+            }
+            fast = cur + nb4 < L && used + nd4 <= 128u && !xa_exact && !xb_exact && plain;
         }
         if (fast) {
 #pragma unroll
-            for (uint32_t q = 0; q < 4u; q++) do_block(b0 + q, q, wsrc, mg[4 * q], mg[4 * q + 1], mg[4 * q + 2], mg[4 * q + 3], std::true_type());
+            for (uint32_t q = 0; q < 4u; q++) do_block(b0 + q, mg[4 * q], mg[4 * q + 1], mg[4 * q + 2], mg[4 * q + 3], std::true_type());
             flush_full();                      // (at most 1023 + 512 bytes are pending here: the ring holds 2048)
             if (used >= 64u) next_buffer();    // (used <= 128 here)
             if (used >= 64u) next_buffer();
@@ -973,11 +995,19 @@ pb_emit_kernel(PbEmitParams P) {
 #pragma unroll
             for (uint32_t q = 0; q < 4u; q++) {
                 if (b0 + q >= nblk || cur >= L) break;
-                do_block(b0 + q, q, wsrc, cmasks[b0 + q].x, cmasks[b0 + q].y, cmasks[b0 + q].z, cmasks[b0 + q].w, std::false_type());
+                do_block(b0 + q, cmasks[b0 + q].x, cmasks[b0 + q].y, cmasks[b0 + q].z, cmasks[b0 + q].w, std::false_type());
                 flush_full();
             }
         }
-        wsrc = wnext;
+        // the last group of a chunk: the next chunk goes down beside it (into the half the chunk before this one used), and
+        // the one after that is requested
+        if (!SEG && (b0 & 15u) == 12u) {
+            const uint32_t c = (b0 >> 4) + 1u;
+            if (c < n_chunks) {
+                stage_chunk(c, nxt);
+                if (c + 1u < n_chunks) nxt = load_chunk(c + 1u);
+            }
+        }
     }
     // ---- "\n+\n": the rest of the ring leaves, the quality line goes straight to the image
     if (lid == 0) put(0u, '\n');
