@@ -126,11 +126,11 @@ static void launch_batches(jk_session& s, StreamCtx* sc, bool pipelined = false)
             Q.stale = s.d_pb_stale[set].as<uint8_t>();
             Q.stale_ctr = s.d_pb_ctr[set].as<uint32_t>() + 2;
             if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));      // the set is free once its emit kernel is done
-            // Both kernels are bound by instruction issue, so running the plan kernel of launch b beside the emit kernel of
-            // launch b - 1 wins little (147 against 153 ms per step on BASELINE configs[4] at 2^21 lanes) and, when the
-            // plan kernel's waves carry fewer than 64 lanes, loses (164 against 155 ms at 2^20 lanes, 172 against 158 at
-            // 2^19): then the kernels take turns.  JK_PB_SERIAL=0/1 to choose.
-            bool pb_serial = s.pb_wave_lanes[b] < 64;
+            // The plan kernel of launch b runs beside the emit kernel of launch b - 1 (8 waves of 64 VGPRs per SIMD leave the
+            // emit kernel's waves room); taking turns instead was ahead by 2-4 % while the plan kernel held 4 x 128 VGPRs and
+            // its waves carried fewer than 64 lanes, and is behind by up to 8 % now (tools/pb_planwaves_probe.sh: four job
+            // shapes).  JK_PB_SERIAL=1 for that schedule.
+            bool pb_serial = false;
             if (const char* e = std::getenv("JK_PB_SERIAL")) pb_serial = std::atoi(e) != 0;
             if (pb_serial && b >= 1) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 1], 0));
             JK_HIP(hipEventRecord(s.events[ev++], s.stream));

@@ -136,18 +136,26 @@ static void finish_pacbio(jk_session& s, uint64_t max_batch_bytes, const PacbioH
     PhaseTimer pt("pacbio: plan, alloc, upload");
     const std::vector<uint64_t>& lane_reads = lp.lane_reads;
     const uint64_t rec_mean = max_hdr + n_digits(max_chrom) + 3 + 2 * (uint64_t)std::ceil(M.len_mean) + 8;
-    // A launch = whole lanes with all their reads.  The plan kernel is a dependent chain per wave and wants four waves
-    // on every SIMD (`slots`), no more (a fifth runs after the others: the launch then takes twice as long) and not many
+    // A launch = whole lanes with all their reads.  The plan kernel is a dependent chain per wave and wants its eight waves
+    // on every SIMD (`slots`), no more (a ninth runs after the others: the launch then takes twice as long) and not many
     // fewer; its waves carry wl = 1..64 lanes each.  So a launch takes slots x wl lanes, with wl the largest power of two
-    // that keeps its expected FASTQ within the batch size (16 GB unless max_batch_bytes says otherwise) -- and when the
-    // run has few lanes with many reads each, a launch still takes `slots` of them if memory allows (up to 96 GB of
-    // image per launch: the scratch is an eighth of that), since a lane's reads cannot be spread over launches.
+    // that keeps its expected FASTQ within the batch size -- and when the run has few lanes with many reads each, a launch
+    // still takes `slots` of them if memory allows (up to 96 GB of image per launch: the scratch is an eighth of that),
+    // since a lane's reads cannot be spread over launches.
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, s.device);
-    uint64_t waves_per_cu = 16;
-    if (const char* e = std::getenv("JK_PB_WAVES_PER_CU")) { const int v = std::atoi(e); if (v >= 4 && v <= 16 && v % 4 == 0) waves_per_cu = (uint64_t)v; }
+    uint64_t waves_per_cu = 4 * JK_PB_PLAN_WAVES;
+    if (const char* e = std::getenv("JK_PB_WAVES_PER_CU")) { const int v = std::atoi(e); if (v >= 4 && v <= 32 && v % 4 == 0) waves_per_cu = (uint64_t)v; }
     const uint64_t slots = (uint64_t)n_cu * waves_per_cu;
-    uint64_t batch_bytes = max_batch_bytes ? max_batch_bytes : (16ULL << 30);
+    // (default batch: 32 GB of FASTQ -- a full launch of 10-kb reads at three reads per lane -- when the device has room for
+    //  two such image slots and their scratch beside everything else, less on a device that is already in use)
+    uint64_t batch_bytes = max_batch_bytes;
+    if (!batch_bytes) {
+        size_t free0 = 0, total0 = 0;
+        dev_mem_info(&free0, &total0);
+        batch_bytes = free0 >= (96ULL << 30) ? (32ULL << 30) : free0 >= (48ULL << 30) ? (16ULL << 30) : (8ULL << 30);
+    }
+    if (const char* e = std::getenv("JK_PB_BATCH_GB")) { const int v = std::atoi(e); if (v >= 1 && v <= 128 && !max_batch_bytes) batch_bytes = (uint64_t)v << 30; }     // (experiments)
     uint64_t max_batch_lanes = 1ULL << 18;
     uint32_t wave_lanes = 64;
     {

@@ -236,11 +236,13 @@ __device__ __forceinline__ uint32_t pb_nt_of_char(uint32_t ch) { return ch == 'T
 // terminating NUL if it equals the string's size, and lies outside the string otherwise (undefined in the reference,
 // refused here unless undefined_as_nul).
 // ---------------------------------------------------------------------------------------------------------------
-// Four waves per SIMD (128 VGPRs; the per-lane set-up phases spill 16 of them, the shared pass-1 loop needs few): the
-// loop is a dependent chain per wave -- multiply-add, output, compares, scalar bookkeeping -- and only other waves fill
-// its gaps (measured on BASELINE configs[4]: 13.8 ms per launch against 28.9 with the 224 VGPRs the compiler would take)
+// Eight waves per SIMD (64 VGPRs; the per-lane set-up phases spill, the shared pass-1 loop needs few): the loop is a
+// dependent chain per wave -- multiply-add, output, compares, scalar bookkeeping -- and only other waves fill its gaps,
+// and at 64 VGPRs the emit kernel's waves find room on the same SIMDs (measured on four job shapes against four waves of
+// 128 VGPRs: +4 to +8 % reads/s, tools/pb_planwaves_probe.sh; 28.9 against 13.8 ms per launch was the step from the 224
+// VGPRs the compiler would take to 128).  api_pacbio.h sizes a launch to this number of waves per SIMD.
 #ifndef JK_PB_PLAN_WAVES
-#define JK_PB_PLAN_WAVES 4
+#define JK_PB_PLAN_WAVES 8
 #endif
 #define JK_PB_PLAN_ATTR __attribute__((amdgpu_waves_per_eu(JK_PB_PLAN_WAVES, JK_PB_PLAN_WAVES)))
 template <bool HAP>
