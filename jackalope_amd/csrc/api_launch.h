@@ -125,7 +125,13 @@ static void launch_batches(jk_session& s, StreamCtx* sc, bool pipelined = false)
             Q.mask_ctr = s.d_pb_ctr[set].as<unsigned long long>();
             Q.stale = s.d_pb_stale[set].as<uint8_t>();
             Q.stale_ctr = s.d_pb_ctr[set].as<uint32_t>() + 2;
-            if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));      // the set is free once its emit kernel is done
+            // the set is free once its emit kernel is done: that of launch b - 2, or (a step queued behind another) of the
+            // last launch of the step before that used the set -- its event still holds that record
+            if (b >= 2) JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[b - 2], 0));
+            else if (s.inflight > 0) {
+                const size_t nb = s.batches.size();
+                for (size_t k = nb; k-- > 0;) if ((int)(k & 1) == set) { JK_HIP(hipStreamWaitEvent(s.stream, s.cp_done[k], 0)); break; }
+            }
             // The plan kernel of launch b runs beside the emit kernel of launch b - 1 (8 waves of 64 VGPRs per SIMD leave the
             // emit kernel's waves room); taking turns instead was ahead by 2-4 % while the plan kernel held 4 x 128 VGPRs and
             // its waves carried fewer than 64 lanes, and is behind by up to 8 % now (tools/pb_planwaves_probe.sh: four job
@@ -330,7 +336,6 @@ static void launch_generate(jk_session& s) {
 // generate_async(): queue one more pass over all batches (at most two in flight); wait(): complete the oldest
 static void launch_generate_async(jk_session& s) {
     if (s.streaming) throw Error(JK_ERR_ARG, "this session streams its output (stream_output): use jk_session_run");
-    if (s.pacbio) throw Error(JK_ERR_UNSUPPORTED, "pipelined steps are implemented for the Illumina sessions");
     if (s.inflight >= 2) throw Error(JK_ERR_ARG, "two steps are in flight already: jk_session_wait first");
     launch_batches(s, nullptr, true);
 }

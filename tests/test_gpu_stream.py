@@ -245,3 +245,28 @@ def test_pipelined_steps_give_the_same_image(ja, O, hs25):
             assert s.fetch(0) == o1 and s.fetch(1) == o2
             s.generate()                          # and the plain call still works afterwards
             assert s.fetch(0) == o1 and s.fetch(1) == o2 and s.timing_ms()["total"] > 0
+
+
+def test_pipelined_pacbio_steps_give_the_same_image(ja, O):
+    """The same for a PacBio session: the first plan kernel of the second pass runs beside the last emit kernel of the
+    first, on the set of records and masks that the first pass's last-but-one launch used."""
+    g = ja.synthetic_genome([900_000], seed=26)
+    n_reads, T = 2400, 300
+    words = ja.seed_words(82, 16 * T)
+    pb = {"custom_read_lengths": [400, 2500, 9000]}
+    o, _, _ = O.pacbio_ref(g, pb, n_reads=n_reads, n_threads=T, words=words)
+    for mbb in (0, 2 << 20):                      # one launch per pass; five or six launches per pass
+        with ja.pacbio(g, None, n_reads, n_threads=T, seed_words=words, max_batch_bytes=mbb, _session=True, **pb) as s:
+            assert (s.n_batches() == 1) == (mbb == 0)
+            s.generate_async()
+            s.generate_async()
+            with pytest.raises(ja.JackalopeHipError):
+                s.generate_async()                # two in flight at most
+            s.wait()
+            assert s.sizes() == ([len(o)], n_reads)
+            s.generate_async()
+            s.wait()
+            s.wait()
+            assert s.fetch(0) == o
+            s.generate()
+            assert s.fetch(0) == o
