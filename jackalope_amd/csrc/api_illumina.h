@@ -354,7 +354,19 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
         if (std::getenv("JK_BATCH_LANES")) first_lanes = 0;
     }
     const uint32_t max_lanes = plan_pools_common(s, a.max_batch_bytes, launch_lanes, lane_cap, lp, Q, 0, first_lanes);
-    const IlluminaPacked packed = pack_illumina_tables(s.tables);
+    // after the tables: haplotype runs served from the mutation tables add the per-lane segment table (JK_HAP_SEGS segments
+    // x 12 bytes x 1024 lanes); every other run the 2 KB expansion table of the packed reference
+    const bool seg_run = s.hap && !s.hap_materialised;
+    const size_t seg_bytes = seg_run ? (size_t)JK_HAP_SEGS * 12 * JK_ILL_BLOCK : 0;
+    const size_t lut_bytes = seg_run ? 0 : 2048;
+    // 8 bytes per alias entry when the tables fit LDS that way (or do not fit either way: they then stay in global memory),
+    // 6 bytes per entry when that is what lets them in (JK_ALIAS6=0/1 to force)
+    const size_t n_info0 = s.tables.info.size(), n_ent0 = s.tables.thresh.size();
+    const size_t bytes8 = n_info0 * 8 + n_ent0 * 8, bytes6 = n_info0 * 8 + n_ent0 * 4 + (n_ent0 + 1) / 2 * 4;
+    const size_t lds_room = 156 * 1024;
+    s.ent6 = bytes8 + seg_bytes + lut_bytes > lds_room && bytes6 + seg_bytes + lut_bytes <= lds_room && s.ev_words <= (uint32_t)JK_MAX_EVW;
+    if (const char* e = std::getenv("JK_ALIAS6")) s.ent6 = std::atoi(e) != 0 && bytes6 + seg_bytes + lut_bytes <= lds_room && s.ev_words <= (uint32_t)JK_MAX_EVW;
+    const IlluminaPacked packed = s.ent6 ? pack_illumina_tables6(s.tables) : pack_illumina_tables(s.tables);
     s.d_tab.upload(packed.tab);
     s.d_tab_lo.upload(packed.lo);
     s.d_mm2.upload(packed.mm2);
@@ -362,11 +374,6 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
     s.d_evw.alloc(2 * s.evw_set * 8);
 
     s.lds_bytes = packed.tab.size() * 4;        // dynamic LDS; the kernel keeps mm2 (2 KB) in static LDS on top
-    // after the tables: haplotype runs served from the mutation tables add the per-lane segment table (JK_HAP_SEGS segments
-    // x 12 bytes x 1024 lanes); every other run the 2 KB expansion table of the packed reference
-    const bool seg_run = s.hap && !s.hap_materialised;
-    const size_t seg_bytes = seg_run ? (size_t)JK_HAP_SEGS * 12 * JK_ILL_BLOCK : 0;
-    const size_t lut_bytes = seg_run ? 0 : 2048;
     // (reads above 480 need the 64-bit event masks, which only the kernels with the tables in global memory have)
     s.lds_tables = s.lds_bytes + seg_bytes + lut_bytes <= 156 * 1024 && s.ev_words <= (uint32_t)JK_MAX_EVW;
     // tables in global memory: their {entry offset, entry count} part (8 bytes per end, position and nucleotide) goes to
@@ -407,7 +414,12 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
         const int lb = (int)s.lds_launch;
         auto allow = [&](const void* k) { JK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lb)); };
 #define JK_K(LDS, NE, HAP, SEG) reinterpret_cast<const void*>(&illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP, SEG>)
-        if (s.lds_tables) {
+#define JK_K6(NE, HAP, SEG) reinterpret_cast<const void*>(&illumina_kernel<true, NE, JK_ILL_BLOCK, HAP, SEG, true>)
+        if (s.lds_tables && s.ent6) {
+            allow(JK_K6(1, false, false)); allow(JK_K6(2, false, false));
+            allow(JK_K6(1, true, true)); allow(JK_K6(2, true, true));
+            allow(JK_K6(1, true, false)); allow(JK_K6(2, true, false));
+        } else if (s.lds_tables) {
             allow(JK_K(true, 1, false, false)); allow(JK_K(true, 2, false, false));
             allow(JK_K(true, 1, true, true)); allow(JK_K(true, 2, true, true));
             allow(JK_K(true, 1, true, false)); allow(JK_K(true, 2, true, false));
@@ -416,6 +428,7 @@ static void plan_pools_and_alloc(jk_session& s, const jk_illumina_args& a, const
             allow(JK_K(false, 1, true, false)); allow(JK_K(false, 2, true, false));
             allow(JK_K(false, 1, false, false)); allow(JK_K(false, 2, false, false));
         }
+#undef JK_K6
 #undef JK_K
     }
 }

@@ -213,7 +213,12 @@ static void launch_batches(jk_session& s, StreamCtx* sc, bool pipelined = false)
         JK_HIP(hipEventRecord(s.events[ev++], gs));
 #define JK_LAUNCH(LDS, NE, HAP, SEG, SH) hipLaunchKernelGGL((illumina_kernel<LDS, NE, JK_ILL_BLOCK, HAP, SEG>), dim3(grid), dim3(block), SH, gs, P)
         const bool seg = s.hap && !s.hap_materialised;       // bases through the mutation tables (else: plain sequences)
-        if (s.lds_tables) {
+#define JK_LAUNCH6(NE, HAP, SEG, SH) hipLaunchKernelGGL((illumina_kernel<true, NE, JK_ILL_BLOCK, HAP, SEG, true>), dim3(grid), dim3(block), SH, gs, P)
+        if (s.lds_tables && s.ent6) {
+            if (seg)        { if (s.n_ends == 2) JK_LAUNCH6(2, true, true, s.lds_launch); else JK_LAUNCH6(1, true, true, s.lds_launch); }
+            else if (s.hap) { if (s.n_ends == 2) JK_LAUNCH6(2, true, false, s.lds_launch); else JK_LAUNCH6(1, true, false, s.lds_launch); }
+            else            { if (s.n_ends == 2) JK_LAUNCH6(2, false, false, s.lds_launch); else JK_LAUNCH6(1, false, false, s.lds_launch); }
+        } else if (s.lds_tables) {
             if (seg)        { if (s.n_ends == 2) JK_LAUNCH(true, 2, true, true, s.lds_launch); else JK_LAUNCH(true, 1, true, true, s.lds_launch); }
             else if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(true, 2, true, false, s.lds_launch); else JK_LAUNCH(true, 1, true, false, s.lds_launch); }
             else            { if (s.n_ends == 2) JK_LAUNCH(true, 2, false, false, s.lds_launch); else JK_LAUNCH(true, 1, false, false, s.lds_launch); }
@@ -222,6 +227,7 @@ static void launch_batches(jk_session& s, StreamCtx* sc, bool pipelined = false)
             else if (s.hap) { if (s.n_ends == 2) JK_LAUNCH(false, 2, true, false, s.lds_launch); else JK_LAUNCH(false, 1, true, false, s.lds_launch); }
             else            { if (s.n_ends == 2) JK_LAUNCH(false, 2, false, false, s.lds_launch); else JK_LAUNCH(false, 1, false, false, s.lds_launch); }
         }
+#undef JK_LAUNCH6
 #undef JK_LAUNCH
         JK_HIP(hipGetLastError());
         JK_HIP(hipEventRecord(s.events[ev++], gs));

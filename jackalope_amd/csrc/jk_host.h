@@ -361,6 +361,31 @@ inline IlluminaPacked pack_illumina_tables(const IlluminaTables& T) {
     return K;
 }
 
+// The same with 6 bytes per entry, for LDS only (kernel flag E6): [info: {offset of the first cut-point word, entry count |
+// offset of the first character pair << 8}][high words of the cut points][{character kept, character of the alias} pairs].
+inline IlluminaPacked pack_illumina_tables6(const IlluminaTables& T) {
+    IlluminaPacked K;
+    K.mm2.assign(256, 0);
+    for (uint32_t q = 0; q < 256; q++) K.mm2[(q + 33u) & 255u] = T.mm_thresh[q];
+    const size_t n_info = T.info.size(), n_ent = T.thresh.size();
+    K.tab.assign(n_info * 2 + n_ent + (n_ent + 1) / 2, 0u);
+    K.lo.resize(std::max<size_t>(n_ent, 1));
+    const uint32_t th0 = (uint32_t)(n_info * 8), qq0 = th0 + (uint32_t)(n_ent * 4);
+    for (size_t i = 0; i < n_info; i++) {
+        const uint32_t first = T.info[i] & 0xffffffu;
+        K.tab[2 * i] = th0 + first * 4u;
+        K.tab[2 * i + 1] = (T.info[i] >> 24) | ((qq0 + first * 2u) << 8);
+    }
+    uint16_t* qq = reinterpret_cast<uint16_t*>(K.tab.data() + n_info * 2 + n_ent);
+    for (size_t e = 0; e < n_ent; e++) {
+        K.lo[e] = (uint32_t)T.thresh[e];
+        K.tab[n_info * 2 + e] = (uint32_t)(T.thresh[e] >> 32);
+        const uint32_t c_self = ((T.quals[e] & 0xffu) + 33u) & 255u, c_alias = ((T.quals[e] >> 8) + 33u) & 255u;
+        qq[e] = (uint16_t)(c_self | (c_alias << 8));
+    }
+    return K;
+}
+
 inline void add_profile(IlluminaTables& T, const jk_illumina_profile& pr) {
     const uint32_t L = pr.read_length;
     const size_t info0 = T.info.size();

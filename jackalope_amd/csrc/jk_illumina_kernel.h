@@ -361,7 +361,9 @@ materialise_haps_kernel(const uint8_t* __restrict__ seq, const uint64_t* __restr
 // SEG = the haplotype's bases are read through the mutation tables, segment by segment; HAP without SEG = every
 // haplotype chromosome was materialised in device memory beforehand (materialise_haps_kernel): the cursor, quota, gamma
 // and barcode logic of a haplotype run over plain contiguous sequences, g.chrom_off / hdr_off indexed by cell.
-template <bool LDS_TAB, uint32_t NE, int BLOCK, bool HAP, bool SEG = HAP>
+// E6 (with LDS_TAB) = the alias entries as two arrays, 6 bytes per entry: the cut points' high words, then {character kept,
+// character of the alias} as byte pairs (IlluminaPacked6 in jk_host.h) -- for pairs of profiles that fit LDS that way only.
+template <bool LDS_TAB, uint32_t NE, int BLOCK, bool HAP, bool SEG = HAP, bool E6 = false>
 __global__ void __launch_bounds__(BLOCK) JK_GEN_ATTR
 illumina_kernel(IlluminaKernelParams P) {
     extern __shared__ __align__(16) uint8_t smem[];
@@ -377,11 +379,12 @@ illumina_kernel(IlluminaKernelParams P) {
 #endif
     if (LDS_TAB) {
         uint32_t* s_tab = reinterpret_cast<uint32_t*>(smem);
-        const uint32_t n_words = 2u * P.n_info + 2u * P.n_entries;
-        // entry offsets become absolute LDS addresses on the way in (one add less per base)
+        const uint32_t n_words = 2u * P.n_info + (E6 ? P.n_entries + (P.n_entries + 1u) / 2u : 2u * P.n_entries);
+        // entry offsets become absolute LDS addresses on the way in (one add less per base); E6: the second word of an
+        // info entry holds the offset of the position's first character pair above its entry count
         const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
         for (uint32_t i = threadIdx.x; i < n_words; i += blockDim.x)
-            s_tab[i] = P.tab[i] + ((i < 2u * P.n_info && !(i & 1u)) ? lds_base : 0u);
+            s_tab[i] = P.tab[i] + (i < 2u * P.n_info ? (!(i & 1u) ? lds_base : (E6 ? lds_base << 8 : 0u)) : 0u);
         T.tab = smem;
     } else {
         // profiles whose alias entries do not fit in LDS (every built-in one but HiSeq 2500 150 bp) still have a small
@@ -848,11 +851,14 @@ illumina_kernel(IlluminaKernelParams P) {
             auto qual_step = [&](uint32_t c8, uint32_t opos, uint64_t x1, bool& mism) -> uint32_t {
                 const uint32_t inf_off = (i * L + opos) * 32u + c8;
                 const uint2 inf = info_lds ? *reinterpret_cast<const uint2*>(smem + inf_off) : *reinterpret_cast<const uint2*>(T.tab + inf_off);
-                const uint32_t ent_off = inf.x, nq = inf.y;
+                const uint32_t ent_off = inf.x, nq = E6 ? (inf.y & 0xffu) : inf.y;
                 const uint32_t idx = alias_index32(x1, nq);
-                const uint32_t eoff = idx * 8u + ent_off;
+                const uint32_t eoff = idx * (E6 ? 4u : 8u) + ent_off;
                 uint32_t th_hi, qp;
-                if (LDS_TAB) {
+                if (E6) {
+                    th_hi = *(const __attribute__((address_space(3))) uint32_t*)(uintptr_t)eoff;
+                    qp = *(const __attribute__((address_space(3))) uint16_t*)(uintptr_t)((inf.y >> 8) + idx * 2u);
+                } else if (LDS_TAB) {
                     const __attribute__((address_space(3))) uint32_t* ep = (const __attribute__((address_space(3))) uint32_t*)(uintptr_t)eoff;
                     th_hi = ep[0]; qp = ep[1];
                 } else {
@@ -867,12 +873,12 @@ illumina_kernel(IlluminaKernelParams P) {
                 if (__builtin_amdgcn_ballot_w64(x2h == th_hi) != 0) {
                     asm volatile("" ::: "memory");
                     if (x2h == th_hi) {
-                        keep = (uint32_t)x2 < P.tab_lo[(eoff - ent_base) >> 3];
+                        keep = (uint32_t)x2 < P.tab_lo[(eoff - ent_base) >> (E6 ? 2 : 3)];
                         const uint32_t k = atomicAdd(P.rare_log, 1u);
                         if (k < JK_RARE_LOG_CAP) P.rare_log[1 + k] = P.rare_lane0 + lane;
                     }
                 }
-                const uint32_t ch8 = keep ? (qp & 0xffffu) : (qp >> 16);
+                const uint32_t ch8 = E6 ? ((keep ? (qp & 0xffu) : (qp >> 8)) << 3) : (keep ? (qp & 0xffffu) : (qp >> 16));
                 const uint64_t mmth = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint8_t*>(s_mm) + ch8);
                 mism = x3 < mmth;
                 return ch8;

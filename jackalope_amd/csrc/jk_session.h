@@ -31,6 +31,7 @@ struct jk_session {
     IlluminaTables tables;
     DevBuf d_tab, d_tab_lo, d_mm2;
     bool lds_tables = false;
+    bool ent6 = false;                     // ... as 6-byte entries (two arrays): kernel flag E6
     size_t lds_bytes = 0, lds_launch = 0, evw_set = 0;
     uint32_t lds_seg_off = 0, lds_lut_off = 0, lds_cell_off = 0xffffffffu;
     bool hap = false;

@@ -10,7 +10,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import jackalope_amd as ja  # noqa: E402
 
-args = sys.argv[1:] or ["HS25", "150", "1", "MSv3", "250", "1", "HS20", "100", "1", "GA2", "75", "1", "HS25", "125", "0"]
+args = sys.argv[1:] or ["HS25", "150", "1", "MSv3", "250", "1", "HS20", "100", "1", "GA2", "75", "1", "HS25", "125", "1", "HS25", "125", "0"]
 lanes = 1 << 20
 genome = ja.synthetic_genome([100_000_000], seed=2)
 words = ja.seed_words(12345, 16 * lanes)
