@@ -836,7 +836,7 @@ pb_emit_kernel(PbEmitParams P) {
         const uint64_t xv = pb_pcg_out(ds0, ds1, ds2, ds3);
         x_lo = (uint32_t)xv; x_hi = (uint32_t)(xv >> 32);
         const uint32_t p3 = x_hi * 3u;
-        pk = __umulhi(x_hi, 3u) | ((x_hi >> 30) << 8);
+        pk = __umulhi(x_hi, 3u) | (__builtin_amdgcn_perm(0u, 0x47414354u, x_hi >> 30) << 8);      // {index of 3, "TCAG"[index of 4] << 8}
         ex = __builtin_amdgcn_ballot_w64(p3 >= P.exact_from || (x_hi << 2) >= P.exact_from) != 0;
     };
     make_buffer(xa_lo, xa_hi, pka, xa_exact);
@@ -883,8 +883,9 @@ pb_emit_kernel(PbEmitParams P) {
     // that this is not the read's last block -- true for all but the last few blocks of a read, and it takes the
     // end-of-read, end-of-window and flush tests (scalar instructions: a SIMD issues one per four clocks, like vector
     // ones, and this kernel has as many of them) out of the block.
-    auto do_block = [&](uint32_t b, uint32_t mvx, uint32_t mvy, uint32_t mvz, uint32_t mvw, auto safe_tag) {
+    auto do_block = [&](uint32_t b, uint32_t mvx, uint32_t mvy, uint32_t mvz, uint32_t mvw, auto safe_tag, auto a_only_tag) {
         constexpr bool SAFE = decltype(safe_tag)::value;
+        constexpr bool A_ONLY = decltype(a_only_tag)::value;        // (SAFE) all draws of the group lie in buffer A
         const uint64_t lo = (uint64_t)mvx | ((uint64_t)mvy << 32), hi = (uint64_t)mvz | ((uint64_t)mvw << 32);
         const uint64_t insm = lo & ~hi, delm = hi & ~lo, keep = ~delm;
         const uint32_t off = pb_mbcnt(insm, pb_mbcnt(keep, 0u));          // bases the positions below this lane's add
@@ -901,7 +902,8 @@ pb_emit_kernel(PbEmitParams P) {
         const uint32_t d = used + pb_mbcnt(evm, 0u);                      // this lane's draw, if it has one: 0..127
         const int baddr = (int)((d << 2) & 0xfcu);                        // (the same for draw d of A and draw d - 64 of B)
         uint32_t pkv;
-        {
+        if (A_ONLY) pkv = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)pka);
+        else {
             const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)pka), pb = (uint32_t)__builtin_amdgcn_ds_bpermute(baddr, (int)pkb);
             pkv = d < 64u ? pa : pb;
         }
@@ -914,7 +916,7 @@ pb_emit_kernel(PbEmitParams P) {
             const uint32_t nidx = is_sub ? 3u : 4u;
             const uint32_t code = runif_index32(((uint64_t)xh << 32) | xl, nidx);
             nulm = __builtin_amdgcn_ballot_w64(code >= nidx) & evm;
-            pkv = (code & 3u) | ((code & 3u) << 8);
+            pkv = (code & 3u) | (base_char(code & 3u) << 8);
         }
         used += ne;
         // ---- source base
@@ -940,19 +942,19 @@ pb_emit_kernel(PbEmitParams P) {
             const uint32_t c3 = pkv & 0xffu;
             const uint32_t sc = c3 + (c3 >= c ? 1u : 0u);
             ch = __builtin_amdgcn_perm(0u, 0x47414354u, my_sub ? sc : c);
-            ich = __builtin_amdgcn_perm(0u, 0x47414354u, pkv >> 8);
+            ich = pkv >> 8;
         } else {
             // characters as the reference's `read` buffer holds them (cmp_map on the reverse strand keeps N and zeroes
             // everything else that is not a base; positions past the window hold what earlier reads left)
             const bool proc = __builtin_amdgcn_inverse_ballot_w64(pm), is_nul = __builtin_amdgcn_inverse_ballot_w64(nulm);
-            const uint32_t c3 = pkv & 3u, c4 = (pkv >> 8) & 3u;
+            const uint32_t c3 = pkv & 3u;
             uint32_t bch, nt;
             if (p >= space) { bch = proc ? P.stale[R.stale_idx + (p - space)] : 0u; nt = pb_nt_of_char(bch); }
             else if (craw < 4u) { bch = base_char(c); nt = c; }
             else { bch = reverse ? (craw == 'N' ? (uint32_t)'N' : 0u) : jk_decode_other(craw); nt = 4u; }
             const uint32_t sub_ch = is_nul ? 0u : (nt < 4u ? base_char(c3 + (c3 >= nt ? 1u : 0u)) : (uint32_t)'N');
             ch = my_sub ? sub_ch : bch;
-            ich = is_nul ? 0u : base_char(c4);
+            ich = is_nul ? 0u : (pkv >> 8);
         }
         const uint32_t ri = (g + off) & (PB_RING - 1u);
         if (__builtin_amdgcn_inverse_ballot_w64(kp)) ring[ri] = (uint8_t)ch;
@@ -966,12 +968,13 @@ pb_emit_kernel(PbEmitParams P) {
         bool fast = cur + 256u < L && (b0 + 4u) * 64u <= space && b0 + 4u < nblk;
         typedef uint32_t pb_u16v __attribute__((ext_vector_type(16)));
         pb_u16v mg = {};
+        uint32_t nd4 = 0;                              // draws of the group
         if (fast) {
             // (the four blocks' masks as one 64-byte scalar load: a read's blocks start on a 64-byte line)
             mg = *reinterpret_cast<const pb_u16v __attribute__((address_space(4)))*>(cmasks + b0);
             // ... and the group's draws fit the two buffers, none of which needs the exact routine, and its 256 source bytes
             // are plain bases (lane l holds four of them)
-            const uint32_t nd4 = (uint32_t)__builtin_popcountll((uint64_t)mg[0] | ((uint64_t)mg[1] << 32)) + (uint32_t)__builtin_popcountll((uint64_t)mg[4] | ((uint64_t)mg[5] << 32)) +
+            nd4 = (uint32_t)__builtin_popcountll((uint64_t)mg[0] | ((uint64_t)mg[1] << 32)) + (uint32_t)__builtin_popcountll((uint64_t)mg[4] | ((uint64_t)mg[5] << 32)) +
                                  (uint32_t)__builtin_popcountll((uint64_t)mg[8] | ((uint64_t)mg[9] << 32)) + (uint32_t)__builtin_popcountll((uint64_t)mg[12] | ((uint64_t)mg[13] << 32));
             bool plain = true;
             if (!SEG) {
@@ -987,9 +990,14 @@ pb_emit_kernel(PbEmitParams P) {
             }
             fast = cur + nb4 < L && used + nd4 <= 128u && !xa_exact && !xb_exact && plain;
         }
-        if (fast) {
+        if (fast && used + nd4 <= 64u) {
 #pragma unroll
-            for (uint32_t q = 0; q < 4u; q++) do_block(b0 + q, mg[4 * q], mg[4 * q + 1], mg[4 * q + 2], mg[4 * q + 3], std::true_type());
+            for (uint32_t q = 0; q < 4u; q++) do_block(b0 + q, mg[4 * q], mg[4 * q + 1], mg[4 * q + 2], mg[4 * q + 3], std::true_type(), std::true_type());
+            flush_full();
+            if (used >= 64u) next_buffer();
+        } else if (fast) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) do_block(b0 + q, mg[4 * q], mg[4 * q + 1], mg[4 * q + 2], mg[4 * q + 3], std::true_type(), std::false_type());
             flush_full();                      // (at most 1023 + 512 bytes are pending here: the ring holds 2048)
             if (used >= 64u) next_buffer();    // (used <= 128 here)
             if (used >= 64u) next_buffer();
@@ -997,7 +1005,7 @@ pb_emit_kernel(PbEmitParams P) {
 #pragma unroll
             for (uint32_t q = 0; q < 4u; q++) {
                 if (b0 + q >= nblk || cur >= L) break;
-                do_block(b0 + q, cmasks[b0 + q].x, cmasks[b0 + q].y, cmasks[b0 + q].z, cmasks[b0 + q].w, std::false_type());
+                do_block(b0 + q, cmasks[b0 + q].x, cmasks[b0 + q].y, cmasks[b0 + q].z, cmasks[b0 + q].w, std::false_type(), std::false_type());
                 flush_full();
             }
         }
