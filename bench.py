@@ -67,6 +67,18 @@ def pmc_traffic(pairs_per_launch):
         return None
 
 
+def pmc_traffic_pacbio(reads_per_launch):
+    """The same for a PacBio launch (plan kernel + emit kernel), from profiles/r03_pmc_pacbio.json: taken on the bench
+    workload, whose launches hold 1.5 M reads; null at another launch size."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_pacbio.json")))
+        if abs(reads_per_launch - 1.5e6) > 0.02 * 1.5e6:
+            return None
+        return int(sum(v["traffic_bytes_per_launch (2*FETCH + WRITE, KB units)"] for v in d.values()))
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
 def bgzf_main(a):
     """Secondary line: the compressed sink.  The R1 FASTQ image of the headline workload (configs[1], 10 M pairs,
     3.3 GB) is BGZF-compressed where it lies in HBM (jk_bgzf_deflate).  A step = one pass over that image."""
@@ -428,7 +440,7 @@ def pacbio_main(a):
                "gbases_per_sec": round(total_bytes[0] / 2 * a.steps / elapsed / 1e9, 2), "step_ms": spread,
                "steps_mode": "one at a time" if a.sync_steps else "pipelined: two steps in flight, the next step's first plan kernel beside this step's last emit kernel",
                "roofline": {"bound": "hbm", "achieved": round(alg / kern_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(alg / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "kernel": "pb_plan_kernel + pb_emit_kernel",
+                            "frac": round(alg / kern_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic_pacbio(reads / n_launch), "kernel": "pb_plan_kernel + pb_emit_kernel",
                             "launches_per_step": n_launch, "kernel_ms": round(kern_s * 1e3, 3), "plan_kernel_ms": round(gen_ms / a.steps / n_launch, 3),
                             "note": "a launch is a plan kernel (pass 1 of its reads: 64 positions per LCG jump-ahead step) and an emit kernel "
                                     "(one wave per read, text straight into the image); kernel_ms = time of a step / launches; "
