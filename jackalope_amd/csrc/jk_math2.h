@@ -91,6 +91,8 @@ JK_HD bool jk_exp(double x, double* out) { return jk_exp_core(x, 0.0, out); }
 JK_HD double jk_pow(double x, double y, bool* ok) {
     const uint64_t ix = jk_d2u(x), iy = jk_d2u(y);
     const uint32_t topx = (uint32_t)(ix >> 52), topy = (uint32_t)(iy >> 52);
+    // pow(+0, y) = +0 for finite y > 0 (glibc's zero-base branch returns x * x): an event probability of exactly 0
+    if (ix == 0 && !(iy >> 63) && (iy << 1) != 0 && (topy & 0x7ffu) != 0x7ffu) return 0.0;
     if (topx - 1u > 0x7fdu || (topy & 0x7ffu) - 0x3beu > 0x7fu) { *ok = false; return 0.0; }
     // log_inline
     const uint64_t tmp = ix - 0x3fe6955500000000ULL;

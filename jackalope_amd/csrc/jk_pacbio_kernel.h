@@ -391,8 +391,10 @@ pb_plan_kernel(PacbioKernelParams P) {
                 cum[2] = jk_pow(P.prob_subst, expo, &ok) + cum[1];
                 if (!ok) err |= JK_KERR_PB_MATH;
                 const double qv = __builtin_round(-10.0 * jk_log10(cum[2]));
-                // (uint64) of a negative value is undefined in the reference; x86-64 gives a huge number -> 93
-                const uint32_t q = (qv < 0 || qv > 93.0) ? 93u : (uint32_t)qv;
+                // (uint64) of a negative or infinite value is undefined in the reference (src/hts_pacbio.h: `uint64 tmp =
+                // std::round(...)`); x86-64 makes a huge number of a negative one -> 93, and 0 of +inf (all three
+                // probabilities exactly 0: cvttsd2si of inf - 2^63 gives 2^63, whose top bit the conversion flips back)
+                const uint32_t q = qv < 0 ? 93u : (qv > 1.8e19 ? 0u : (qv > 93.0 ? 93u : (uint32_t)qv));
                 (side == 0 ? qual_left : qual_right) = q + 33u;
             }
             if (err) break;

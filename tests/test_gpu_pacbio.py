@@ -186,3 +186,7 @@ def test_blocks_whose_draws_span_both_buffers(ja, O):
     check_ref(ja, O, g, 400, 8, {"ins_prob": 0.45, "del_prob": 0.05, "sub_prob": 0.45, "custom_read_lengths": [3000, 9000]})
     check_ref(ja, O, g, 400, 8, {"ins_prob": 0.001, "del_prob": 0.001, "sub_prob": 0.001, "custom_read_lengths": [3000, 9000]})
     check_ref(ja, O, g, 400, 8, {"ins_prob": 1e-6, "del_prob": 1e-6, "sub_prob": 1e-6, "custom_read_lengths": [6000]})
+    # probabilities of exactly 0 (pow(0, y) = 0): an error-free read, and each kind of event switched off on its own
+    check_ref(ja, O, g, 200, 8, {"ins_prob": 0.0, "del_prob": 0.0, "sub_prob": 0.0, "custom_read_lengths": [6000]})
+    check_ref(ja, O, g, 200, 8, {"ins_prob": 0.0, "custom_read_lengths": [3000]})
+    check_ref(ja, O, g, 200, 8, {"del_prob": 0.0, "sub_prob": 0.0, "custom_read_lengths": [3000]})
