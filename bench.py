@@ -483,6 +483,11 @@ def hap_main(a):
     dev.close()
     hs = random_haplotypes_flat(ref, n_haps, seed=31)
     pairs_per_gpu = n_chroms * chrom_len * 30 // 300 // 8
+    if not a.sync_steps:
+        # steps two in flight, as on the headline line: every launch leaves an eighth of the CUs to the compaction before it
+        os.environ.setdefault("JK_FIRST_LAUNCH_FULL", "0")
+        if a.lanes == DEFAULT_LANES:
+            a.lanes = 4 * 224 * 1024
     lanes_per_gpu = a.lanes
     lanes, n_reads = lanes_per_gpu * world, 2 * pairs_per_gpu * world
     words = ja.seed_words(12345, hs.seed_budget(lanes))
