@@ -496,7 +496,18 @@ illumina_kernel(IlluminaKernelParams P) {
             // ---- chrom_indels_frag: chromosome, fragment length, fragment start (hts_illumina.cpp:192-217)
             // (HAP: IlluminaHaplotypes::one_read's cursor search, hts_illumina.cpp:505-525 -- the first cell at
             //  or after the current one with reads left)
-            while (ci < n_cells && ccnt == 0) { ci++; if (ci < n_cells) ccnt = P.chrom_reads[(size_t)ci * P.chrom_stride + lane]; }
+            // (four cells per look: a haplotype run has as many cells as haplotypes x chromosomes and a lane's few dozen pairs
+            //  leave most of them empty, so cell by cell the cursor paid a dependent global load for every one of them)
+            while (ci < n_cells && ccnt == 0) {
+                uint32_t q[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; k++) q[k] = ci + 1u + k < n_cells ? P.chrom_reads[(size_t)(ci + 1u + k) * P.chrom_stride + lane] : 0u;
+                if (q[0]) { ci += 1u; ccnt = q[0]; }
+                else if (q[1]) { ci += 2u; ccnt = q[1]; }
+                else if (q[2]) { ci += 3u; ccnt = q[2]; }
+                else { ci += 4u; ccnt = q[3]; }
+                if (ci > n_cells) ci = n_cells;
+            }
             if (ci >= n_cells) { made = quota; break; }         // `finished`
             if (HAP) {
                 const uint32_t hap = ci / P.g.n_chroms;
